@@ -1,0 +1,75 @@
+"""ctypes loader for liblandiff_hip.so (the only compute backend; fails loudly if absent)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void_p, c_float, c_double
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblandiff_hip.so")
+
+
+class LandiffHipError(RuntimeError):
+    pass
+
+
+class Epilogue(Structure):
+    """Mirror of ld_epilogue_t (include/landiff_hip.h)."""
+
+    _fields_ = [
+        ("bias", c_void_p),
+        ("act", c_int32),
+        ("mul", c_void_p),
+        ("ldmul", c_int64),
+        ("resid", c_void_p),
+        ("ldr", c_int64),
+        ("resid_f32", c_int32),
+        ("gate", c_void_p),
+        ("gate_bstride", c_int64),
+        ("gate_off_img", c_int64),
+        ("gate_off_txt", c_int64),
+        ("rows_per_batch", c_int32),
+        ("text_len", c_int32),
+        ("add2", c_void_p),
+        ("ldadd", c_int64),
+        ("out_f32", c_int32),
+    ]
+
+
+_lib = None
+
+I64 = c_int64
+P = c_void_p
+
+# name -> argtypes; every symbol declared in include/landiff_hip.h must be listed here
+SIGNATURES: dict[str, list] = {
+    "ld_version": [],
+    "ld_last_error": [],
+    "ld_gemm_bf16": [P, I64, P, P, I64, I64, I64, I64, POINTER(Epilogue), P],
+    "ld_conv_cl_bf16": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, POINTER(Epilogue), P],
+}
+
+
+def load():
+    """Load the shared library (once).  Raises LandiffHipError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LandiffHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_char_p if name == "ld_last_error" else c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().ld_last_error()
+        raise LandiffHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds liblandiff_hip.so for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OUT=../liblandiff_hip.so
+SRCS=$(ls ld_*.hip)
+mkdir -p obj
+pids=()
+for s in $SRCS; do
+  o=obj/${s%.hip}.o
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ ld_common.h -nt "$o" ] || [ ../../include/landiff_hip.h -nt "$o" ]; then
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result -c "$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT obj/*.o
+echo "built $OUT"

@@ -1,0 +1,24 @@
+// Error plumbing + version for liblandiff_hip.so.
+#include "ld_common.h"
+#include "../../include/landiff_hip.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+int ld_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int ld_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ld_set_error(LD_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return LD_OK;
+}
+
+LD_API int ld_version(void) { return LD_ABI_VERSION; }
+LD_API const char* ld_last_error(void) { return g_err; }

@@ -1,0 +1,96 @@
+// Shared device/host helpers for the LanDiff gfx950 kernels.
+// Everything here is CDNA4-only (wave64, MFMA 32x32x16 bf16, LDS-DMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LD_API extern "C" __attribute__((visibility("default")))
+
+// ---- error plumbing (thread-local message, negative return codes) ----
+enum {
+  LD_OK = 0,
+  LD_ERR_INVALID = -1,   // bad argument (shape/alignment/null pointer)
+  LD_ERR_LAUNCH = -2,    // hipLaunch error
+  LD_ERR_UNSUPPORTED = -3
+};
+int ld_set_error(int code, const char* fmt, ...);
+int ld_check_launch(const char* what);
+
+#define LD_REQUIRE(cond, ...)                                  \
+  do {                                                         \
+    if (!(cond)) return ld_set_error(LD_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (4 VGPR)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+// ---- bf16 <-> f32 (round-to-nearest-even, same as torch's c10::BFloat16) ----
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
+  uint32_t r = 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)((u + r) >> 16);
+}
+// round an f32 value to the nearest bf16 and return it as f32 (emulates a bf16 op output)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- activations (fp32 math, matching torch's CPU/CUDA formulas) ----
+__device__ __forceinline__ float act_gelu_tanh(float x) {
+  const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
+  const float kKappa = 0.044715f;
+  float inner = kBeta * (x + kKappa * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float act_gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+}
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+enum { LD_ACT_NONE = 0, LD_ACT_GELU_TANH = 1, LD_ACT_GELU_ERF = 2, LD_ACT_SILU = 3, LD_ACT_TANH = 4 };
+
+__device__ __forceinline__ float apply_act(int act, float x) {
+  switch (act) {
+    case LD_ACT_GELU_TANH: return act_gelu_tanh(x);
+    case LD_ACT_GELU_ERF: return act_gelu_erf(x);
+    case LD_ACT_SILU: return act_silu(x);
+    case LD_ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+
+// ---- wave-level reductions (64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id (8 XCDs; block b runs on XCD b % 8).
+// Consecutive logical ids land on the same XCD so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int q = nwg / nx, r = nwg % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

@@ -1,0 +1,351 @@
+// bf16 MFMA GEMM / implicit-GEMM convolution for gfx950 with fused epilogues.
+//
+//   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] )        (W in nn.Linear layout, K contiguous)
+//
+// Replaces (reference op sites):
+//   sat ColumnParallelLinear/RowParallelLinear + bias + GELU-tanh + gated residual
+//   (landiff/diffusion/dit_video_concat.py:568-629,1234-1237,1357-1370),
+//   nn.Linear in the TiTok decoder (landiff/tokenizer/modules/blocks.py:164-219,253-261),
+//   ContextParallelCausalConv3d / Conv2d (landiff/diffusion/vae_modules/cp_enc_dec.py:416-473,
+//   590-633; landiff/diffusion/semantic_models/modules/vq_gan_blocks.py:90-148).
+//
+// Structure (MI355X-first, not a translation of a warp-32 tiling):
+//   * 128x128 output tile per 256-thread workgroup, 4 wave64 as 2x2, each wave 64x64 =
+//     2x2 v_mfma_f32_32x32x16_bf16 accumulators (64 acc VGPRs), BK = 64.
+//   * A and W tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B/lane, no VGPR
+//     round trip), double buffered (2 x 32 KB), one barrier per K-tile.
+//   * LDS image is lane-linear (DMA constraint); bank conflicts on the ds_read_b128 fragment
+//     reads are removed by XOR-swizzling the 16-B chunk index with ((row>>1)&7) on the
+//     *source* address and on the read (both-sides rule).
+//   * Convolution is the same kernel with a different A-row address generator: the input is a
+//     zero-bordered channels-last tensor [T+kT-1][H+kH-1][W+kW-1][Cin], so every tap is a plain
+//     128-byte row read: no bounds checks, coalesced (B,T,H,W,C) loads.
+//   * Epilogue goes through wave-private LDS so that global stores / residual loads are
+//     16-byte, row-contiguous.
+//   * blockIdx is remapped so that consecutive tiles of one A panel sit on one XCD (private L2).
+#include "ld_common.h"
+#include "../../include/landiff_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KB per operand per stage
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
+constexpr int CW_STRIDE = 68;                    // fp32 row stride of the epilogue staging tile
+constexpr int SMEM_BYTES = 4 * 64 * CW_STRIDE * 4;  // 69632 >= 2 * STAGE_BYTES (65536)
+
+struct GemmParams {
+  const bf16_t* A;
+  const bf16_t* W;
+  void* out;
+  const bf16_t* bias;
+  const bf16_t* mul;
+  const void* resid;
+  const bf16_t* gate;
+  const bf16_t* add2;
+  int M, N, K;
+  long lda, ldo, ldr, ldmul, ldadd;
+  int act;
+  int out_f32, resid_f32;
+  int rows_per_batch, text_len;
+  long gate_bstride, gate_off_img, gate_off_txt;
+  // conv (channels-last, zero-bordered input)
+  int H, W_, Hp, Wp, Cin, kH, kW;   // output H,W; padded input Hp,Wp
+};
+
+__device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)g,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void ld_gemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, nbm * nbn);
+  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+
+  // ---- per-thread source row offsets (4 rows of A, 4 rows of W per K-tile) ----
+  long offA[4], offW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);   // source-side swizzle
+    int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+    if (CONV) {
+      const int hw = p.H * p.W_;
+      const int t = gm / hw, rem = gm - t * hw;
+      const int h = rem / p.W_, w = rem - h * p.W_;
+      offA[i] = (((long)t * p.Hp + h) * p.Wp + w) * p.Cin + chunk * 8;
+    } else {
+      offA[i] = (long)gm * p.lda + chunk * 8;
+    }
+    offW[i] = (long)gn * p.K + chunk * 8;
+  }
+
+  const int nk = p.K / BK;
+  const int cpt = CONV ? p.Cin / BK : 1;   // K-tiles per tap
+
+  auto stage = [&](int buf, int kt) {
+    long koffA;
+    if (CONV) {
+      const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+      const int khw = p.kH * p.kW;
+      const int dt = tap / khw, r2 = tap - dt * khw;
+      const int dh = r2 / p.kW, dw = r2 - dh * p.kW;
+      koffA = (((long)dt * p.Hp + dh) * p.Wp + dw) * p.Cin + c0;
+    } else {
+      koffA = (long)kt * BK;
+    }
+    const long koffW = (long)kt * BK;
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(p.A + offA[i] + koffA, base + (wave * 4 + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(p.W + offW[i] + koffW, base + TILE_BYTES + (wave * 4 + i) * 1024);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read addresses (bytes within an operand tile), swizzle key is k-step independent
+  int rdA[2], rdB[2], keyA[2], keyB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wr * 64 + i * 32 + (lane & 31);
+    const int rb = wc * 64 + i * 32 + (lane & 31);
+    rdA[i] = ra * 128; keyA[i] = (ra >> 1) & 7;
+    rdB[i] = rb * 128; keyB[i] = (rb >> 1) & 7;
+  }
+  const int khalf = lane >> 5;
+
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and releases the other buffer
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = kk * 2 + khalf;
+      bf16x8_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *(const bf16x8_t*)(sa + rdA[i] + ((c ^ keyA[i]) << 4));
+        b[i] = *(const bf16x8_t*)(sb + rdB[i] + ((c ^ keyB[i]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: accumulators -> wave-private LDS (fp32) -> row-contiguous 16-B stores ----
+  float* cw = (float*)smem + wave * (64 * CW_STRIDE);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = j * 32 + (lane & 31);
+        cw[row * CW_STRIDE + col] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  const bool vec_ok = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) &&
+                      (p.resid == nullptr || (p.ldr & 7) == 0) &&
+                      (p.mul == nullptr || (p.ldmul & 7) == 0) &&
+                      (p.add2 == nullptr || (p.ldadd & 7) == 0);
+#pragma unroll 1
+  for (int ps = 0; ps < 8; ++ps) {
+    const int row = ps * 8 + (lane >> 3);
+    const int col0 = (lane & 7) * 8;
+    const int gm = m0 + wr * 64 + row;
+    const int gn0 = n0 + wc * 64 + col0;
+    if (gm >= p.M || gn0 >= p.N) continue;
+    float v[8];
+    {
+      const f32x4_t lo = *(const f32x4_t*)(cw + row * CW_STRIDE + col0);
+      const f32x4_t hi = *(const f32x4_t*)(cw + row * CW_STRIDE + col0 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+    }
+    const int nvalid = (p.N - gn0) < 8 ? (p.N - gn0) : 8;
+    const bf16_t* gate_row = nullptr;
+    if (p.gate) {
+      const int b = gm / p.rows_per_batch;
+      const int rin = gm - b * p.rows_per_batch;
+      gate_row = p.gate + b * p.gate_bstride + (rin < p.text_len ? p.gate_off_txt : p.gate_off_img);
+    }
+    if (vec_ok) {
+      float bias[8], mulv[8], gt[8], rs[8], ad[8];
+      if (p.bias) {
+        const u32x4_t bw = *(const u32x4_t*)(p.bias + gn0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias[2 * e] = bf_lo(bw[e]); bias[2 * e + 1] = bf_hi(bw[e]); }
+      }
+      if (p.mul) {
+        const u32x4_t mw = *(const u32x4_t*)(p.mul + (long)gm * p.ldmul + gn0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mulv[2 * e] = bf_lo(mw[e]); mulv[2 * e + 1] = bf_hi(mw[e]); }
+      }
+      if (gate_row) {
+        const u32x4_t gw = *(const u32x4_t*)(gate_row + gn0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gt[2 * e] = bf_lo(gw[e]); gt[2 * e + 1] = bf_hi(gw[e]); }
+      }
+      if (p.resid) {
+        if (p.resid_f32) {
+          const f32x4_t r0 = *(const f32x4_t*)((const float*)p.resid + (long)gm * p.ldr + gn0);
+          const f32x4_t r1 = *(const f32x4_t*)((const float*)p.resid + (long)gm * p.ldr + gn0 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { rs[e] = r0[e]; rs[4 + e] = r1[e]; }
+        } else {
+          const u32x4_t rw = *(const u32x4_t*)((const bf16_t*)p.resid + (long)gm * p.ldr + gn0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { rs[2 * e] = bf_lo(rw[e]); rs[2 * e + 1] = bf_hi(rw[e]); }
+        }
+      }
+      if (p.add2) {
+        const u32x4_t aw = *(const u32x4_t*)(p.add2 + (long)gm * p.ldadd + gn0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ad[2 * e] = bf_lo(aw[e]); ad[2 * e + 1] = bf_hi(aw[e]); }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e];
+        if (p.bias) x += bias[e];
+        x = rbf(x);                                   // bf16 Linear/conv output
+        if (p.act) x = rbf(apply_act(p.act, x));
+        if (p.mul) x = rbf(x * mulv[e]);
+        if (gate_row) x = rbf(x * gt[e]);
+        if (p.resid) { x = rs[e] + x; if (!p.out_f32) x = rbf(x); }
+        if (p.add2) { x = x + ad[e]; if (!p.out_f32) x = rbf(x); }
+        v[e] = x;
+      }
+      if (p.out_f32) {
+        float* o = (float*)p.out + (long)gm * p.ldo + gn0;
+        *(f32x4_t*)o = (f32x4_t){v[0], v[1], v[2], v[3]};
+        *(f32x4_t*)(o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+      } else {
+        u32x4_t ow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ow[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+        *(u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0) = ow;
+      }
+    } else {
+      for (int e = 0; e < nvalid; ++e) {
+        const int gn = gn0 + e;
+        float x = v[e];
+        if (p.bias) x += bf2f(p.bias[gn]);
+        x = rbf(x);
+        if (p.act) x = rbf(apply_act(p.act, x));
+        if (p.mul) x = rbf(x * bf2f(p.mul[(long)gm * p.ldmul + gn]));
+        if (gate_row) x = rbf(x * bf2f(gate_row[gn]));
+        if (p.resid) {
+          const float r = p.resid_f32 ? ((const float*)p.resid)[(long)gm * p.ldr + gn]
+                                      : bf2f(((const bf16_t*)p.resid)[(long)gm * p.ldr + gn]);
+          x = r + x; if (!p.out_f32) x = rbf(x);
+        }
+        if (p.add2) { x = x + bf2f(p.add2[(long)gm * p.ldadd + gn]); if (!p.out_f32) x = rbf(x); }
+        if (p.out_f32) ((float*)p.out)[(long)gm * p.ldo + gn] = x;
+        else ((bf16_t*)p.out)[(long)gm * p.ldo + gn] = f2bf(x);
+      }
+    }
+  }
+}
+
+int launch(const GemmParams& p, bool conv, hipStream_t stream) {
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  dim3 grid(nbm * nbn), block(256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ld_gemm_kernel<false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)ld_gemm_kernel<true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_set = true;
+  }
+  if (conv) hipLaunchKernelGGL(ld_gemm_kernel<true>, grid, block, SMEM_BYTES, stream, p);
+  else hipLaunchKernelGGL(ld_gemm_kernel<false>, grid, block, SMEM_BYTES, stream, p);
+  return ld_check_launch("ld_gemm");
+}
+
+int fill_epilogue(GemmParams& p, const ld_epilogue_t* e) {
+  p.bias = nullptr; p.mul = nullptr; p.resid = nullptr; p.gate = nullptr; p.add2 = nullptr;
+  p.act = 0; p.out_f32 = 0; p.resid_f32 = 0; p.rows_per_batch = 1 << 30; p.text_len = 0;
+  p.gate_bstride = 0; p.gate_off_img = 0; p.gate_off_txt = 0;
+  p.ldr = p.ldmul = p.ldadd = 0;
+  if (!e) return LD_OK;
+  LD_REQUIRE(e->act >= 0 && e->act <= LD_ACT_TANH, "ld_gemm: bad activation %d", e->act);
+  p.bias = (const bf16_t*)e->bias; p.act = e->act;
+  p.mul = (const bf16_t*)e->mul; p.ldmul = e->ldmul;
+  p.resid = e->resid; p.ldr = e->ldr; p.resid_f32 = e->resid_f32;
+  p.gate = (const bf16_t*)e->gate;
+  p.add2 = (const bf16_t*)e->add2; p.ldadd = e->ldadd;
+  p.out_f32 = e->out_f32;
+  if (e->rows_per_batch > 0) p.rows_per_batch = e->rows_per_batch;
+  p.text_len = e->text_len;
+  p.gate_bstride = e->gate_bstride; p.gate_off_img = e->gate_off_img; p.gate_off_txt = e->gate_off_txt;
+  LD_REQUIRE(!(p.gate && !p.resid) || true, "unused");
+  return LD_OK;
+}
+
+}  // namespace
+
+LD_API int ld_gemm_bf16(const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
+                        int64_t M, int64_t N, int64_t K, const ld_epilogue_t* epi, void* stream) {
+  LD_REQUIRE(A && W && out, "ld_gemm_bf16: null pointer");
+  LD_REQUIRE(M > 0 && N > 0 && K > 0, "ld_gemm_bf16: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+  LD_REQUIRE(K % BK == 0, "ld_gemm_bf16: K=%ld must be a multiple of %d", (long)K, BK);
+  LD_REQUIRE(lda % 8 == 0, "ld_gemm_bf16: lda=%ld must be a multiple of 8 elements", (long)lda);
+  LD_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 15) == 0,
+             "ld_gemm_bf16: pointers must be 16-byte aligned");
+  LD_REQUIRE(M * (int64_t)N < (1LL << 40) && M < (1LL << 31) && N < (1LL << 31), "ld_gemm_bf16: problem too large");
+  GemmParams p{};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.out = out;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = lda; p.ldo = ldo;
+  int rc = fill_epilogue(p, epi);
+  if (rc) return rc;
+  return launch(p, false, (hipStream_t)stream);
+}
+
+LD_API int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int64_t ldo,
+                           int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                           int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, void* stream) {
+  LD_REQUIRE(in_padded && Wt && out, "ld_conv_cl_bf16: null pointer");
+  LD_REQUIRE(T > 0 && H > 0 && W > 0 && Cout > 0, "ld_conv_cl_bf16: empty problem");
+  LD_REQUIRE(Cin % BK == 0, "ld_conv_cl_bf16: Cin=%ld must be a multiple of %d (zero-pad channels)", (long)Cin, BK);
+  LD_REQUIRE(kT >= 1 && kH >= 1 && kW >= 1 && (kH & 1) && (kW & 1), "ld_conv_cl_bf16: bad kernel size");
+  LD_REQUIRE(T * H * W < (1LL << 31), "ld_conv_cl_bf16: too many output positions");
+  GemmParams p{};
+  p.A = (const bf16_t*)in_padded; p.W = (const bf16_t*)Wt; p.out = out;
+  p.M = (int)(T * H * W); p.N = (int)Cout; p.K = (int)(kT * kH * kW * Cin); p.lda = 0; p.ldo = ldo;
+  p.H = (int)H; p.W_ = (int)W; p.Hp = (int)(H + kH - 1); p.Wp = (int)(W + kW - 1);
+  p.Cin = (int)Cin; p.kH = (int)kH; p.kW = (int)kW;
+  int rc = fill_epilogue(p, epi);
+  if (rc) return rc;
+  return launch(p, true, (hipStream_t)stream);
+}
