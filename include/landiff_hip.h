@@ -73,6 +73,21 @@ int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int64_t ld
                     int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                     int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, void* stream);
 
+/* Fused attention, head_dim 64: O = softmax(scale * Q K^T [+ frame mask]) V.
+ * Q, K: bf16 [B*H][Npad][64]; Vt: bf16 [B*H][64][Npad] (V transposed, keys contiguous);
+ * O: bf16, element (b, n, h*64 + d) at O + b*o_batch_stride + n*o_row_stride + h*64 + d.
+ * Npad % 128 == 0; rows/keys in [N, Npad) must be zero-filled.  fid_q/fid_k (int32 [Npad], or
+ * both NULL) select the frame-block mask allowed(q,kv) <=> fid_k[kv] <= fid_q[q]; padding keys
+ * carry INT32_MAX; kt_min/kt_max are the per-64-key-tile min/max of fid_k.
+ * Replaces sat attention_fn_default/F.scaled_dot_product_attention behind AdaLNMixin.attention_fn
+ * (landiff/diffusion/dit_video_concat.py:636-664) and flex_attention with VideoDecoderMask
+ * (landiff/tokenizer/modules/blocks.py:172-212, flex_attention_mask.py:193-335). */
+int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
+                     int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
+                     int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
+                     const int32_t* fid_q, const int32_t* fid_k,
+                     const int32_t* kt_min, const int32_t* kt_max, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

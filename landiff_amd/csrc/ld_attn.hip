@@ -1,0 +1,306 @@
+// Flash-style fused attention for gfx950, head_dim 64, bf16 in / fp32 accumulate / bf16 out.
+//
+// Replaces:
+//   sat attention_fn_default -> F.scaled_dot_product_attention on the joint text+video sequence
+//   (landiff/diffusion/dit_video_concat.py:636-664; called from :587,:1308), and
+//   flex_attention(block_mask=VideoDecoderMask) in the TiTok decoder
+//   (landiff/tokenizer/modules/blocks.py:172-212; mask landiff/tokenizer/modules/flex_attention_mask.py:193-335,
+//   whose closed form is  allowed(q,kv) <=> fid[kv] <= fid[q]  -- SURVEY.md Appendix B).
+//
+// MI355X-first structure:
+//   * one workgroup = 4 wave64 = 128 query rows (32 per wave); K and V^T tiles of 64 keys are
+//     brought HBM->LDS by LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier/tile.
+//   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 ("swapped" product): a lane then owns ONE query
+//     column (lane&31) and 32 of the 64 keys, so the softmax row reductions are lane-local
+//     plus a single exchange with lane^32 (v_permlane32_swap).
+//   * the K rows fed to the MFMA are permuted (bits 2<->3 of the row index swapped in the LDS
+//     read address -- free), which makes the 8 accumulator registers [8*ks .. 8*ks+7] exactly
+//     the 8 consecutive keys the PV MFMA wants as its B fragment: no cross-lane traffic, no
+//     P round trip through LDS.
+//   * V is consumed as V^T [d][key] (written in that layout by the qkv-split kernel), so the
+//     PV A-fragment is a plain ds_read_b128; O^T accumulates per (d-row, q-column) and the
+//     online-softmax rescale is a per-lane scalar multiply.
+//   * LDS tiles are lane-linear (DMA) with the 16-B chunk XOR-swizzled by ((row>>1)&7) on the
+//     source address and on the read: conflict-free ds_read_b128.
+//   * frame-block mask: per-KV-tile [min,max] frame ids let a workgroup skip fully masked
+//     tiles (no load, no MFMA) and apply the element mask only on the few straddling tiles.
+#include "ld_common.h"
+#include "../../include/landiff_hip.h"
+
+namespace {
+
+constexpr int QB = 128;   // query rows per workgroup
+constexpr int KT = 64;    // keys per tile
+constexpr int D = 64;
+constexpr int KTILE_BYTES = KT * D * 2;       // 8 KB
+constexpr int STAGE_BYTES = 2 * KTILE_BYTES;  // K + V^T
+constexpr float NEG_BIG = -1.0e30f;
+
+struct AttnParams {
+  const bf16_t* Q;    // [BH][Npad][64]
+  const bf16_t* K;    // [BH][Npad][64]
+  const bf16_t* Vt;   // [BH][64][Npad]
+  bf16_t* O;          // [B][Nq][H*64] (row stride o_rs, batch stride o_bs)
+  int B, H, Nq, Nk, Npad;
+  long o_bs, o_rs;
+  float c;            // softmax_scale * log2(e)
+  const int* fid_q;   // [Npad] or null
+  const int* fid_k;   // [Npad] or null (padding keys must carry INT_MAX)
+  const int* kt_min;  // [Npad/64]
+  const int* kt_max;
+};
+
+__device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)g,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float lane32_max(float x) {
+  // max(x, value of lane^32)
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float lane32_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ int swap23(int i) {
+  return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
+}
+
+__global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + 64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int nqb = p.Npad / QB;
+  const int nkt_all = (p.Nk + KT - 1) / KT;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = bid / nqb, qb = bid - bh * nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  const bf16_t* Qb = p.Q + (long)bh * p.Npad * D;
+  const bf16_t* Kb = p.K + (long)bh * p.Npad * D;
+  const bf16_t* Vb = p.Vt + (long)bh * D * p.Npad;
+
+  const int q = qb * QB + wave * 32 + (lane & 31);   // this lane's query row
+  if (qb * QB >= p.Nq) return;                        // whole block past the end (uniform)
+
+  // ---- frame ids of the queries; block/wave ranges ----
+  const bool masked = p.fid_k != nullptr;
+  int qfid = 0, wqmin = 0, wqmax = 0, bqmax = 0;
+  if (masked) {
+    const int qc = q < p.Nq ? q : p.Nq - 1;
+    qfid = p.fid_q[qc];
+    int mn = qfid, mx = qfid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = min(mn, __shfl_xor(mn, o, 64));
+      mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    wqmin = mn; wqmax = mx;
+    int* red = (int*)(smem + 2 * STAGE_BYTES);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    bqmax = max(max(red[0], red[1]), max(red[2], red[3]));
+  }
+
+  // ---- Q fragments (B operand of K Q^T): lane = query column, 8 consecutive d per k-step ----
+  bf16x8_t qf[4];
+  {
+    const bf16_t* qrow = Qb + (long)q * D + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(qrow + kk * 16);
+  }
+
+  // ---- LDS-DMA source offsets: waves 0,1 stage K (rows = keys), waves 2,3 stage V^T (rows = d) ----
+  long goff[4];
+  int ldsoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = wave * 4 + i;            // 0..15 (1 KB pieces)
+    const int r = (idx & 7) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    if (idx < 8) goff[i] = (long)r * D + chunk * 8;          // + kv0 * D
+    else goff[i] = (long)r * p.Npad + chunk * 8;             // + kv0
+    ldsoff[i] = (idx < 8 ? 0 : KTILE_BYTES) + (idx & 7) * 1024;
+  }
+  auto stage = [&](int buf, int t) {
+    const long kv0 = (long)t * KT;
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = wave * 4 + i;
+      const bf16_t* src = (idx < 8) ? (Kb + kv0 * D + goff[i]) : (Vb + kv0 + goff[i]);
+      glds16(src, base + ldsoff[i]);
+    }
+  };
+  auto next_tile = [&](int t) {
+    ++t;
+    if (masked) { while (t < nkt_all && p.kt_min[t] > bqmax) ++t; }
+    return t;
+  };
+
+  // fragment read addresses
+  int kaddr[2], kkey[2], vaddr[2], vkey[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int key = i * 32 + swap23(lane & 31);
+    kaddr[i] = key * 128; kkey[i] = (key >> 1) & 7;
+    const int d = i * 32 + (lane & 31);
+    vaddr[i] = KTILE_BYTES + d * 128; vkey[i] = (d >> 1) & 7;
+  }
+
+  f32x16_t o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m = NEG_BIG, lsum = 0.f;
+
+  int t = -1;
+  t = next_tile(t);
+  if (t < nkt_all) stage(0, t);
+  int buf = 0;
+  while (t < nkt_all) {
+    const int tn = next_tile(t);
+    __syncthreads();
+    if (tn < nkt_all) stage(buf ^ 1, tn);
+    const char* sb = smem + buf * STAGE_BYTES;
+
+    bool skip = false, need_mask = false;
+    if (masked) {
+      const int tmin = p.kt_min[t], tmax = p.kt_max[t];
+      skip = tmin > wqmax;
+      need_mask = tmax > wqmin;
+    } else {
+      need_mask = (t + 1) * KT > p.Nk;
+    }
+    if (!skip) {
+      // ---- S^T = K Q^T ----
+      f32x16_t st[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[i][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int c = kk * 2 + hi;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8_t a = *(const bf16x8_t*)(sb + kaddr[i] + ((c ^ kkey[i]) << 4));
+          st[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], st[i], 0, 0, 0);
+        }
+      }
+      // register r of st[i] holds key  t*64 + i*32 + (r>>3)*16 + hi*8 + (r&7)
+      if (need_mask) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int key0 = t * KT + i * 32 + g * 16 + hi * 8;
+            if (masked) {
+              const int4 f0 = *(const int4*)(p.fid_k + key0);
+              const int4 f1 = *(const int4*)(p.fid_k + key0 + 4);
+              const int f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (f[e] > qfid) st[i][g * 8 + e] = NEG_BIG;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (key0 + e >= p.Nk) st[i][g * 8 + e] = NEG_BIG;
+            }
+          }
+      }
+      // ---- online softmax (per query column; lane and lane^32 share the row) ----
+      float mx = st[0][0];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[i][r]);
+      mx = lane32_max(mx);
+      const float mnew = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m - mnew) * p.c);
+      const float mc = mnew * p.c;
+      m = mnew;
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[i][r], p.c, -mc));
+          st[i][r] = pv;
+          psum += pv;
+        }
+      lsum = lsum * alpha + psum;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      // ---- O^T += V^T P^T ----
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4_t pw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          pw[e] = pack_bf16x2(st[ks >> 1][(ks & 1) * 8 + 2 * e], st[ks >> 1][(ks & 1) * 8 + 2 * e + 1]);
+        const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
+        const int c = ks * 2 + hi;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8_t a = *(const bf16x8_t*)(sb + vaddr[i] + ((c ^ vkey[i]) << 4));
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[i], 0, 0, 0);
+        }
+      }
+    }
+    t = tn;
+    buf ^= 1;
+  }
+
+  // ---- finalize: O = O^T / l, write bf16 rows ----
+  const float ltot = lane32_sum(lsum);
+  const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
+  if (q < p.Nq) {
+    bf16_t* orow = p.O + (long)b * p.o_bs + (long)q * p.o_rs + h * D;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = i * 32 + 8 * g + 4 * hi;
+        u32x2_t w2;
+        w2[0] = pack_bf16x2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
+        w2[1] = pack_bf16x2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+        *(u32x2_t*)(orow + d0) = w2;
+      }
+  }
+}
+
+}  // namespace
+
+LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
+                            int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
+                            int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
+                            const int32_t* fid_q, const int32_t* fid_k,
+                            const int32_t* kt_min, const int32_t* kt_max, void* stream) {
+  LD_REQUIRE(Q && K && Vt && O, "ld_attn_fwd_bf16: null pointer");
+  LD_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "ld_attn_fwd_bf16: empty problem");
+  LD_REQUIRE(Npad % QB == 0 && Npad >= Nq && Npad >= Nk, "ld_attn_fwd_bf16: Npad=%ld must be a multiple of %d and >= Nq,Nk", (long)Npad, QB);
+  LD_REQUIRE((fid_q == nullptr) == (fid_k == nullptr), "ld_attn_fwd_bf16: fid_q and fid_k go together");
+  LD_REQUIRE(!fid_k || (kt_min && kt_max), "ld_attn_fwd_bf16: masked attention needs kt_min/kt_max");
+  LD_REQUIRE(o_row_stride % 4 == 0 && ((uintptr_t)O & 7) == 0, "ld_attn_fwd_bf16: output alignment");
+  AttnParams p{};
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.B = (int)B; p.H = (int)H; p.Nq = (int)Nq; p.Nk = (int)Nk; p.Npad = (int)Npad;
+  p.o_bs = o_batch_stride; p.o_rs = o_row_stride;
+  p.c = softmax_scale * 1.4426950408889634f;
+  p.fid_q = fid_q; p.fid_k = fid_k; p.kt_min = kt_min; p.kt_max = kt_max;
+  const int nqb = (int)(Npad / QB);
+  dim3 grid((unsigned)(B * H * nqb)), block(256);
+  hipLaunchKernelGGL(ld_attn_kernel, grid, block, 0, (hipStream_t)stream, p);
+  return ld_check_launch("ld_attn_fwd_bf16");
+}

@@ -103,3 +103,19 @@ def conv_cl(x_padded: torch.Tensor, w: torch.Tensor, T: int, H: int, W: int,
     check(lib.ld_conv_cl_bf16(_ptr(x_padded), _ptr(w), _ptr(out), out.stride(-2), T, H, W, Cin, Cout,
                               kT, kH, kW, ctypes.byref(e), _stream()), "ld_conv_cl_bf16")
     return out
+
+
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, Nq: int, Nk: int,
+             scale: float, fid_q=None, fid_k=None, kt_min=None, kt_max=None) -> torch.Tensor:
+    """q,k [B,H,Npad,64]; vt [B,H,64,Npad]; out [B,N,H*64] (bf16).  Optional frame mask arrays (int32)."""
+    _bf16(q, "q"); _bf16(k, "k"); _bf16(vt, "vt"); _bf16(out, "out")
+    B, H, Npad, D = q.shape
+    assert D == 64 and k.shape == q.shape and tuple(vt.shape) == (B, H, 64, Npad)
+    assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous() and out.stride(-1) == 1
+    assert out.shape[0] == B and out.shape[2] == H * 64
+    lib = _lib.load()
+    check(lib.ld_attn_fwd_bf16(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), B, H, Nq, Nk, Npad,
+                               out.stride(0), out.stride(1), float(scale),
+                               _ptr(fid_q), _ptr(fid_k), _ptr(kt_min), _ptr(kt_max), _stream()),
+          "ld_attn_fwd_bf16")
+    return out

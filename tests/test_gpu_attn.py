@@ -1,0 +1,62 @@
+"""GPU parity of the fused attention kernel against a plain torch fp32 reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(x, Npad):  # [B,H,N,64] -> zero padded [B,H,Npad,64]
+    B, H, N, D = x.shape
+    out = torch.zeros(B, H, Npad, D, device=x.device, dtype=x.dtype)
+    out[:, :, :N] = x
+    return out
+
+
+def _run(cuda, B, H, N, fid=None, seed=0, spike=False):
+    from landiff_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    q = torch.randn(B, H, N, 64, generator=g).to(cuda, torch.bfloat16)
+    k = torch.randn(B, H, N, 64, generator=g).to(cuda, torch.bfloat16)
+    v = torch.randn(B, H, N, 64, generator=g).to(cuda, torch.bfloat16)
+    if spike:  # force a late running-max jump (exercises the online-softmax rescale)
+        k[:, :, N - 3] = q[:, :, 5] * 4
+    Npad = (N + 127) // 128 * 128
+    qp, kp = _pack(q, Npad), _pack(k, Npad)
+    vt = _pack(v, Npad).transpose(2, 3).contiguous()
+    out = torch.zeros(B, N, H * 64, device=cuda, dtype=torch.bfloat16)
+    kw = {}
+    mask = None
+    if fid is not None:
+        fq = torch.full((Npad,), 0, dtype=torch.int32)
+        fq[:N] = torch.from_numpy(fid)
+        fk = torch.full((Npad,), np.iinfo(np.int32).max, dtype=torch.int32)
+        fk[:N] = torch.from_numpy(fid)
+        kt = fk.view(-1, 64)
+        kw = dict(fid_q=fq.to(cuda), fid_k=fk.to(cuda), kt_min=kt.min(1).values.to(cuda).contiguous(),
+                  kt_max=kt.max(1).values.to(cuda).contiguous())
+        f = torch.from_numpy(fid).to(cuda)
+        mask = f[None, :] <= f[:, None]  # [q, kv]
+    ops.attn_fwd(qp, kp, vt, out, N, N, 0.125, **kw)
+    s = (q.float() @ k.float().transpose(-1, -2)) * 0.125
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    ref = (torch.softmax(s, -1) @ v.float()).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+    err = (out.float() - ref).abs().max().item()
+    return err
+
+
+@pytest.mark.parametrize("B,H,N", [(1, 1, 128), (2, 3, 200), (1, 2, 1000), (1, 1, 64 * 5 + 17)])
+def test_attn_full(cuda, B, H, N):
+    assert _run(cuda, B, H, N) < 2e-2
+
+
+def test_attn_rescale_branch(cuda):
+    assert _run(cuda, 1, 2, 700, spike=True) < 2e-2
+
+
+def test_attn_frame_mask(cuda):
+    # TiTok decoder layout: T frames x tpf visual tokens, then I tokens (fid 0), then P tokens per frame
+    T, tpf, nI, nP = 5, 90, 22, 7
+    fid = np.concatenate([np.repeat(np.arange(T), tpf), np.zeros(nI, np.int64), np.repeat(np.arange(1, T), nP)]).astype(np.int32)
+    assert _run(cuda, 1, 2, len(fid), fid=fid, seed=3) < 2e-2
