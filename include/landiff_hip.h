@@ -88,6 +88,112 @@ int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
                      const int32_t* fid_q, const int32_t* fid_k,
                      const int32_t* kt_min, const int32_t* kt_max, void* stream);
 
+/* ---- HBM-bound small-batch kernels (ld_llm.hip) ---- */
+
+/* y[b][n] = epi(sum_k in_act(x[b][k]) * W[n][k]), 1 <= B <= 4, weights streamed once (one wave per row).
+ * bf16 weights: result rounds to bf16 (Linear output), then act, then `* bf16(W2 x)` (gated MLP,
+ * LlamaMLP2: landiff/llm/modules/transformer_blocks.py:67-88), then `resid + y`.  w_f32: fp32 weights,
+ * x and out fp32 (GPT head, landiff/llm/models/transformer.py:115-118).  in_act is applied to x (bf16-rounded),
+ * e.g. the SiLU in front of adaLN_modulation (landiff/diffusion/dit_video_concat.py:499-503). */
+int ld_gemv(const void* x, int64_t ldx, int32_t x_f32, const void* W, const void* W2, int32_t w_f32,
+            const void* bias, const void* resid, int64_t ldr, void* out, int64_t ldo, int32_t out_f32,
+            int64_t B, int64_t N, int64_t K, int32_t in_act, int32_t act, void* stream);
+
+/* RMSNorm (transformer_blocks.py:22-40): bf16 rows [rows][D], fp32 weight, fp32 math, bf16 out. */
+int ld_rmsnorm_bf16(const void* x, const float* w, void* out, int64_t rows, int64_t D, float eps, void* stream);
+
+/* Final LayerNorm of GPT.sample (transformer.py:112-114): bf16 rows (stride ldx) -> fp32, fp32 affine. */
+int ld_layernorm_bf16_to_f32(const void* x, int64_t ldx, const float* w, const float* b, float* out,
+                             int64_t rows, int64_t D, float eps, void* stream);
+
+/* apply_rope (landiff/modules/pos_emb.py:16-46) on q,k of qkv [B][m][3][H][128] at positions *pos + j, and KV append
+ * into k_cache/v_cache [B][Lmax][H][128] (replaces the torch.cat growth of transformer_blocks.py:153-164). */
+int ld_llm_rope_append(const void* qkv, const float* cos_t, const float* sin_t, const int32_t* pos,
+                       void* q_out, void* k_cache, void* v_cache, int64_t B, int64_t m, int64_t H,
+                       int64_t Lmax, void* stream);
+
+/* Attention of query j (position *pos + j) over keys [0, *pos + j] (transformer_blocks.py:166-186):
+ * bf16 scores, bf16(score / sqrt(128)), fp32 softmax -> bf16 p, bf16 output [B][m][H][128]. */
+int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
+                   int64_t B, int64_t m, int64_t H, int64_t Lmax, void* stream);
+
+/* nn.Embedding lookup of *token (fp32 table [V][D]) -> bf16 features [B][D] (landiff/llm/modules/tokenizer.py:10-55). */
+int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B, int64_t D, void* stream);
+
+/* lm_model.py:417-454: logits [2][V] = (cond, uncond) -> CFG `u + s*(c-u)` (guided), / temperature, optional
+ * restriction to allowed[*pos + 1][1 .. 1+allowed[..][0]], softmax -> probs [V].  cfg_logits (optional) gets the CFG logits. */
+int ld_llm_logits_to_probs(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided,
+                           float scale, float temperature, const int32_t* pos, const int32_t* allowed,
+                           int64_t allowed_stride, void* stream);
+
+/* After torch.multinomial: forced-token override (forced[*pos + 1] >= 0), record sampled visual tokens, ++*pos
+ * (the elif chain of lm_model.py:455-508). */
+int ld_llm_decode_advance(const int64_t* sampled, const int32_t* forced, int32_t* pos, int64_t* token,
+                          int64_t* out_tokens, int32_t* out_count, void* stream);
+
+/* ---- normalisation kernels (ld_norm.hip) ---- */
+
+/* LayerNorm over D (fp32 statistics) with optional AdaLN modulate `x*(1+scale)+shift` (bf16 ops) whose vectors are
+ * picked per row: batch = row / rows_per_batch, region = text if (row % rows_per_batch) < text_len else image;
+ * vector = mod + batch*mod_bstride + {shift,scale}_{img,txt}.  (dit_video_concat.py:388,577-586,601-611;
+ * also nn.LayerNorm in TiTok blocks.py:292-304 with fp32 in / bf16 out.) */
+int ld_layernorm(const void* x, int64_t ldx, int32_t x_f32, const void* w, const void* b, void* out, int64_t ldo,
+                 int32_t out_f32, int64_t rows, int64_t D, float eps, const void* mod, int64_t mod_bstride,
+                 int64_t shift_img, int64_t scale_img, int64_t shift_txt, int64_t scale_txt,
+                 int64_t rows_per_batch, int64_t text_len, void* stream);
+
+/* qkv [B*N][3*H*64] (thirds q|k|v, sat SelfAttention layout) -> Q,K [B][H][Npad][64] (zero padded) and
+ * V^T [B][H][64][Npad].  mode 0: LayerNorm(64, eps) on q,k heads (dit_video_concat.py:649-653);
+ * mode 1: interleaved-pair RoPE with cos/sin [N][32] (blocks.py:172-180, pos_emb.py:16-46). */
+int ld_qkv_split(const void* qkv, void* Q, void* K, void* Vt, int64_t B, int64_t N, int64_t H, int64_t Npad,
+                 int32_t mode, const void* q_w, const void* q_b, const void* k_w, const void* k_b, float eps,
+                 const float* cos_t, const float* sin_t, void* stream);
+
+/* GroupNorm statistics of channels-last x [F][P][C]: stats[f][g] += (sum, sum of squares) in double (zero it first). */
+int ld_groupnorm_stats(const void* x, double* stats, int64_t F, int64_t P, int64_t C, int64_t G, void* stream);
+
+/* y = swish?( GN(x) [* zy + zb] ) written into the interior of a zero-bordered channels-last buffer
+ * [F][T+tpad][H+2*hpad][W+2*wpad][C]; zy/zb [Tz][Hz][Wz][C] are conv_y(zq)/conv_b(zq) at latent resolution, gathered
+ * with SpatialNorm3D's nearest rule incl. the first-frame split for odd T (cp_enc_dec.py:546-569); GroupNorm(32,
+ * eps 1e-6) + swish of vq_gan_blocks.py:29-38,90-148 when zy is NULL. */
+int ld_groupnorm_apply(const void* x, void* out_padded, const double* stats, const void* gamma, const void* beta,
+                       const void* zy, const void* zb, int64_t F, int64_t T, int64_t H, int64_t W, int64_t C,
+                       int64_t G, int64_t Tz, int64_t Hz, int64_t Wz, int64_t tpad, int64_t hpad, int64_t wpad,
+                       int32_t swish, float eps, void* stream);
+
+/* ---- layout / elementwise kernels (ld_elem.hip) ---- */
+
+/* x [B][T][C][H][W] f32 (-> bf16, + sem [T][C][H][W] bf16 for the control net, dit_video_concat.py:991)
+ * -> patch rows [B*T*(H/p)*(W/p)][C*p*p] bf16 for the patch-embed GEMM (:47-62). */
+int ld_patchify(const float* x, const void* sem, void* out, int64_t B, int64_t T, int64_t C, int64_t H, int64_t W,
+                int64_t p, void* stream);
+
+/* unpatchify (:392-410) + Denoiser.forward `net*c_out + x*c_skip` (denoiser.py:25-41) + CFG `u + s*(c-u)`
+ * (guiders.py:75-79): lin [2][T*hp*wp][C*p*p] bf16 (uncond, cond), x/out [T][C][H][W] f32. */
+int ld_unpatchify_cfg(const void* lin, const float* x, float* out, int64_t T, int64_t C, int64_t H, int64_t W,
+                      int64_t p, float c_out, float c_skip, float scale, void* stream);
+
+/* out = a*x + b*y + c*z (y, z optional), products rounded separately, summed left to right (sampling.py:613-644,771-781). */
+int ld_axpbypcz(float* out, const float* x, float a, const float* y, float b, const float* z, float c, int64_t n, void* stream);
+
+/* timestep_embedding (sgm/modules/diffusionmodules/util.py:207-233): t [B] f32 -> [B][dim] bf16 (cos || sin). */
+int ld_timestep_embedding(const float* t, void* out, int64_t B, int64_t dim, float max_period, void* stream);
+
+/* Place a channels-last tensor in [F][Ti][Hi][Wi][Cin] into the interior of a zero-bordered buffer
+ * [F][To+tpad][Ho+2*hpad][Wo+2*wpad][Cout].  mode 0 copy (+channel zero pad); mode 1 nearest x2 (time too when
+ * time_up, first frame single for odd Ti: Upsample3D, cp_enc_dec.py:605-627); mode 2 PixelShuffle(2). */
+int ld_place_cl(const void* in, void* out_padded, int64_t F, int64_t Ti, int64_t Hi, int64_t Wi, int64_t Cin,
+                int64_t Cout, int32_t mode, int32_t time_up, int64_t tpad, int64_t hpad, int64_t wpad, void* stream);
+
+/* dif_infer.py:37-49 + landiff/utils.py:327-331: x [P][ldx] bf16 (3 channels) -> uint8 [P][3] (truncation) and,
+ * optionally, the fp32 video [3][P] in [0,1]. */
+int ld_to_uint8(const void* x, int64_t ldx, uint8_t* out, float* video, int64_t P, void* stream);
+
+/* f32 latent ([T][C][H][W] if src_tchw else [C][T][H][W]) -> bf16 channels-last [T][H][W][Cpad], value bf16(bf16(x)*mul)
+ * (dif_infer.py:251 `1/scale_factor * latent` on the bf16 samples). */
+int ld_latent_to_cl(const float* x, void* out, int64_t T, int64_t C, int64_t H, int64_t W, int64_t Cpad, float mul,
+                    int32_t src_tchw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ class Epilogue(Structure):
 _lib = None
 
 I64 = c_int64
+I32 = c_int32
 P = c_void_p
 
 # name -> argtypes; every symbol declared in include/landiff_hip.h must be listed here
@@ -48,6 +49,25 @@ SIGNATURES: dict[str, list] = {
     "ld_gemm_bf16": [P, I64, P, P, I64, I64, I64, I64, POINTER(Epilogue), P],
     "ld_conv_cl_bf16": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, POINTER(Epilogue), P],
     "ld_attn_fwd_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_float, P, P, P, P, P],
+    "ld_gemv": [P, I64, I32, P, P, I32, P, P, I64, P, I64, I32, I64, I64, I64, I32, I32, P],
+    "ld_rmsnorm_bf16": [P, P, P, I64, I64, c_float, P],
+    "ld_layernorm_bf16_to_f32": [P, I64, P, P, P, I64, I64, c_float, P],
+    "ld_llm_rope_append": [P, P, P, P, P, P, P, I64, I64, I64, I64, P],
+    "ld_llm_kv_attn": [P, P, P, P, P, I64, I64, I64, I64, P],
+    "ld_llm_embed": [P, P, P, I64, I64, P],
+    "ld_llm_logits_to_probs": [P, P, P, I64, I32, c_float, c_float, P, P, I64, P],
+    "ld_llm_decode_advance": [P, P, P, P, P, P, P],
+    "ld_layernorm": [P, I64, I32, P, P, P, I64, I32, I64, I64, c_float, P, I64, I64, I64, I64, I64, I64, I64, P],
+    "ld_qkv_split": [P, P, P, P, I64, I64, I64, I64, I32, P, P, P, P, c_float, P, P, P],
+    "ld_groupnorm_stats": [P, P, I64, I64, I64, I64, P],
+    "ld_groupnorm_apply": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I32, c_float, P],
+    "ld_patchify": [P, P, P, I64, I64, I64, I64, I64, I64, P],
+    "ld_unpatchify_cfg": [P, P, P, I64, I64, I64, I64, I64, c_float, c_float, c_float, P],
+    "ld_axpbypcz": [P, P, c_float, P, c_float, P, c_float, I64, P],
+    "ld_timestep_embedding": [P, P, I64, I64, c_float, P],
+    "ld_place_cl": [P, P, I64, I64, I64, I64, I64, I64, I32, I32, I64, I64, I64, P],
+    "ld_to_uint8": [P, I64, P, P, I64, P],
+    "ld_latent_to_cl": [P, P, I64, I64, I64, I64, I64, c_float, I32, P],
 }
 
 

@@ -1,0 +1,411 @@
+// HBM-bound small-batch kernels: weight-streaming GEMV (batch <= 4), RMSNorm, RoPE + KV append +
+// KV attention (head_dim 128), embedding gather, logits -> probabilities.
+//
+// Replaces: LlamaTransformerBlock / TransformerBlock.local_kvcache_inference
+// (landiff/llm/modules/transformer_blocks.py:22-40,67-88,128-236), GPT.sample (landiff/llm/models/transformer.py:91-119),
+// apply_rope (landiff/modules/pos_emb.py:16-46), the per-step logits math of Semantic1DLM.sample
+// (landiff/llm/models/lm_model.py:417-454), and the batch-2 Linear layers of the DiT's conditioning path
+// (time_embed / adaLN_modulation, landiff/diffusion/dit_video_concat.py:568,764-768).
+//
+// MI355X notes: the decode step is pure weight streaming (4.06 GB bf16 per step); every weight row is
+// read exactly once with 16-byte loads straight into VGPRs (no LDS round trip for an operand that is
+// not shared across waves), one wave64 per output row, activations (<= 4 x K bf16) stay in L1/L2.
+// All per-step scalars (position, token) live in device memory so the whole step is graph-capturable.
+#include "ld_common.h"
+#include "../../include/landiff_hip.h"
+
+namespace {
+
+constexpr int MAXB = 4;
+
+// ---------------------------------------------------------------------------------------------
+// GEMV: y[b][n] = epi( sum_k in_act(x[b][k]) * W[n][k] ), one wave per output row.
+// ---------------------------------------------------------------------------------------------
+struct GemvParams {
+  const void* x;        // [B][ldx] bf16 or f32
+  const void* W;        // [N][K] bf16 or f32
+  const void* W2;       // optional second matrix (gated MLP: act(W x) * (W2 x))
+  const bf16_t* bias;   // [N] or null
+  const void* resid;    // [B][ldr] or null (bf16, or f32 when out_f32)
+  void* out;            // [B][ldo]
+  int B, N, K;
+  long ldx, ldo, ldr;
+  int x_f32, w_f32, out_f32;
+  int in_act, act;
+};
+
+template <int B, bool WF32>
+__global__ __launch_bounds__(256) void ld_gemv_kernel(GemvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= p.N) return;
+  float acc[B], acc2[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) { acc[b] = 0.f; acc2[b] = 0.f; }
+  const int nchunk = p.K >> 3;   // 8 elements per chunk
+  for (int c = lane; c < nchunk; c += 64) {
+    float w[8], w2[8];
+    if (WF32) {
+      const f32x4_t a = *(const f32x4_t*)((const float*)p.W + (long)n * p.K + c * 8);
+      const f32x4_t b4 = *(const f32x4_t*)((const float*)p.W + (long)n * p.K + c * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { w[e] = a[e]; w[4 + e] = b4[e]; }
+    } else {
+      const u32x4_t a = __builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)p.W + (long)n * p.K + c * 8));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { w[2 * e] = bf_lo(a[e]); w[2 * e + 1] = bf_hi(a[e]); }
+      if (p.W2) {
+        const u32x4_t a2 = __builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)p.W2 + (long)n * p.K + c * 8));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { w2[2 * e] = bf_lo(a2[e]); w2[2 * e + 1] = bf_hi(a2[e]); }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float xv[8];
+      if (p.x_f32) {
+        const f32x4_t a = *(const f32x4_t*)((const float*)p.x + b * p.ldx + c * 8);
+        const f32x4_t b4 = *(const f32x4_t*)((const float*)p.x + b * p.ldx + c * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xv[e] = a[e]; xv[4 + e] = b4[e]; }
+      } else {
+        const u32x4_t a = *(const u32x4_t*)((const bf16_t*)p.x + b * p.ldx + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xv[2 * e] = bf_lo(a[e]); xv[2 * e + 1] = bf_hi(a[e]); }
+      }
+      if (p.in_act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = rbf(apply_act(p.in_act, xv[e]));
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[b] = fmaf(xv[e], w[e], acc[b]);
+      if (!WF32 && p.W2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc2[b] = fmaf(xv[e], w2[e], acc2[b]);
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    acc[b] = wave_sum(acc[b]);
+    if (!WF32 && p.W2) acc2[b] = wave_sum(acc2[b]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float v = acc[b];
+      if (p.bias) v += bf2f(p.bias[n]);
+      if (!WF32) v = rbf(v);                         // bf16 Linear output
+      if (p.act) v = rbf(apply_act(p.act, v));
+      if (!WF32 && p.W2) v = rbf(v * rbf(acc2[b]));
+      if (p.resid) {
+        if (p.out_f32) v = ((const float*)p.resid)[b * p.ldr + n] + v;
+        else v = rbf(bf2f(((const bf16_t*)p.resid)[b * p.ldr + n]) + v);
+      }
+      if (p.out_f32) ((float*)p.out)[b * p.ldo + n] = v;
+      else ((bf16_t*)p.out)[b * p.ldo + n] = f2bf(v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm / LayerNorm over short rows (fp32 math), one wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ld_rmsnorm_kernel(const bf16_t* x, const float* w, bf16_t* out,
+                                                         int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const bf16_t* xr = x + (long)r * D;
+  float ss = 0.f;
+  for (int c = lane; c < (D >> 3); c += 64) {
+    const u32x4_t a = *(const u32x4_t*)(xr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float lo = bf_lo(a[e]), hi = bf_hi(a[e]); ss += lo * lo + hi * hi; }
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)D + eps);
+  for (int c = lane; c < (D >> 3); c += 64) {
+    const u32x4_t a = *(const u32x4_t*)(xr + c * 8);
+    const f32x4_t w0 = *(const f32x4_t*)(w + c * 8), w1 = *(const f32x4_t*)(w + c * 8 + 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(a[e]) * rs; v[2 * e + 1] = bf_hi(a[e]) * rs; }
+    u32x4_t o;
+    o[0] = pack_bf16x2(v[0] * w0[0], v[1] * w0[1]); o[1] = pack_bf16x2(v[2] * w0[2], v[3] * w0[3]);
+    o[2] = pack_bf16x2(v[4] * w1[0], v[5] * w1[1]); o[3] = pack_bf16x2(v[6] * w1[2], v[7] * w1[3]);
+    *(u32x4_t*)(out + (long)r * D + c * 8) = o;
+  }
+}
+
+// final LayerNorm of GPT.sample: bf16 rows (row stride ldx) -> fp32, fp32 affine
+__global__ __launch_bounds__(256) void ld_ln_f32out_kernel(const bf16_t* x, long ldx, const float* w, const float* b,
+                                                           float* out, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const bf16_t* xr = x + (long)r * ldx;
+  float s = 0.f, ss = 0.f;
+  for (int i = lane; i < D; i += 64) { const float v = bf2f(xr[i]); s += v; }
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+  for (int i = lane; i < D; i += 64) { const float d = bf2f(xr[i]) - mean; ss += d * d; }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)D + eps);
+  for (int i = lane; i < D; i += 64) out[(long)r * D + i] = (bf2f(xr[i]) - mean) * rs * w[i] + b[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoPE on q,k + KV append.  qkv [B][m][3][H][128] bf16; cache K/V [B][Lmax][H][128];
+// position of token j = *pos + j.  q_out [B][m][H][128].
+// ---------------------------------------------------------------------------------------------
+__global__ void ld_rope_append_kernel(const bf16_t* qkv, const float* cos_t, const float* sin_t, const int* pos_ptr,
+                                      bf16_t* q_out, bf16_t* kc, bf16_t* vc, int B, int m, int H, int Lmax) {
+  const int D = 128;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (b, j, h, pair)
+  const int total = B * m * H * (D / 2);
+  if (idx >= total) return;
+  const int pr = idx % (D / 2);
+  const int h = (idx / (D / 2)) % H;
+  const int j = (idx / (D / 2) / H) % m;
+  const int b = idx / (D / 2) / H / m;
+  const int pos = *pos_ptr + j;
+  const float c = cos_t[pos * (D / 2) + pr], s = sin_t[pos * (D / 2) + pr];
+  const long base = (((long)(b * m + j) * 3) * H + h) * D + 2 * pr;
+  const long hd = (long)H * D;
+  const float qa = bf2f(qkv[base]), qb = bf2f(qkv[base + 1]);
+  const float ka = bf2f(qkv[base + hd]), kb = bf2f(qkv[base + hd + 1]);
+  const long qo = ((long)(b * m + j) * H + h) * D + 2 * pr;
+  q_out[qo] = f2bf(qa * c - qb * s);
+  q_out[qo + 1] = f2bf(qa * s + qb * c);
+  const long co = (((long)b * Lmax + pos) * H + h) * D + 2 * pr;
+  kc[co] = f2bf(ka * c - kb * s);
+  kc[co + 1] = f2bf(ka * s + kb * c);
+  vc[co] = qkv[base + 2 * hd];
+  vc[co + 1] = qkv[base + 2 * hd + 1];
+}
+
+// ---------------------------------------------------------------------------------------------
+// KV attention, head_dim 128: query j (position *pos + j) attends keys [0, *pos + j].
+// Mirrors the reference's dtype flow: bf16 scores, bf16 (score / sqrt(d)), fp32 softmax -> bf16 p, bf16 out.
+// grid (B*H, m), 256 threads; scores staged in LDS (fp32, up to Lmax entries).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ld_kv_attn_kernel(const bf16_t* q, const bf16_t* kc, const bf16_t* vc,
+                                                         const int* pos_ptr, bf16_t* out, int B, int m, int H, int Lmax) {
+  extern __shared__ float sc[];       // [Lmax] scores, then [2][128] partial outputs + 8 reduction slots
+  const int D = 128;
+  const int bh = blockIdx.x, j = blockIdx.y;
+  const int b = bh / H, h = bh - b * H;
+  const int L = *pos_ptr + j + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* qv = q + ((long)(b * m + j) * H + h) * D;
+  // 16 lanes x 8 dims per key, 4 keys per wave iteration
+  const int sub = lane & 15, kq = lane >> 4;
+  float qreg[8];
+  {
+    const u32x4_t a = *(const u32x4_t*)(qv + sub * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { qreg[2 * e] = bf_lo(a[e]); qreg[2 * e + 1] = bf_hi(a[e]); }
+  }
+  const float inv_sqrt_d = 0.08838834764831845f;   // 1/sqrt(128)
+  float lmax = -3.0e38f;
+  for (int k0 = wave * 4; k0 < L; k0 += 16) {
+    const int key = k0 + kq;
+    float d = 0.f;
+    if (key < L) {
+      const u32x4_t a = *(const u32x4_t*)(kc + (((long)b * Lmax + key) * H + h) * D + sub * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d = fmaf(qreg[2 * e], bf_lo(a[e]), d); d = fmaf(qreg[2 * e + 1], bf_hi(a[e]), d); }
+    }
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+    if (key < L) {
+      const float s = rbf(rbf(d) * inv_sqrt_d);    // einsum -> bf16, then "/ sqrt(d)" -> bf16
+      if (sub == 0) sc[key] = s;
+      lmax = fmaxf(lmax, s);
+    }
+  }
+  float* red = sc + Lmax;
+  lmax = wave_max(lmax);
+  if (lane == 0) red[wave] = lmax;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float lsum = 0.f;
+  for (int k = tid; k < L; k += 256) { const float e = __expf(sc[k] - mx); sc[k] = e; lsum += e; }
+  lsum = wave_sum(lsum);
+  __syncthreads();
+  if (lane == 0) red[4 + wave] = lsum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  // out[d] = sum_k bf16(p_k) * v[k][d]; thread -> (d = tid & 127, key parity = tid >> 7)
+  const int d = tid & 127, par = tid >> 7;
+  float acc = 0.f;
+  for (int k = par; k < L; k += 2) {
+    const float pk = rbf(sc[k] * inv);
+    acc = fmaf(pk, bf2f(vc[(((long)b * Lmax + k) * H + h) * D + d]), acc);
+  }
+  float* part = red + 8;
+  part[par * 128 + d] = acc;
+  __syncthreads();
+  if (tid < 128) out[((long)(b * m + j) * H + h) * D + tid] = f2bf(part[tid] + part[128 + tid]);
+}
+
+// token embedding rows (fp32 table) -> bf16 features, same token for every batch row
+__global__ void ld_embed_kernel(const float* table, const long* token, bf16_t* out, int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const long t = *token;
+  out[i] = f2bf(table[t * D + (i % D)]);
+}
+
+// logits [2][V] (cond, uncond) or [1][V] -> probs [V]: CFG, /temperature, optional restriction, softmax.
+// Single block; V <= a few thousand.  (lm_model.py:417-454)
+__global__ __launch_bounds__(1024) void ld_logits_to_probs_kernel(const float* logits, float* probs, float* cfg_logits,
+                                                                  int V, int guided, float scale, float temperature,
+                                                                  const int* pos_ptr, const int* allowed, int n_allowed_stride) {
+  __shared__ float red[32];
+  const int tid = threadIdx.x;
+  const int* al = nullptr;
+  int nal = 0;
+  if (allowed) {
+    al = allowed + (long)(*pos_ptr + 1) * n_allowed_stride;   // table indexed by the position being generated
+    nal = al[0];
+  }
+  float mx = -3.0e38f;
+  for (int i = tid; i < V; i += blockDim.x) {
+    float l = logits[i];
+    if (guided) { const float u = logits[V + i]; l = u + scale * (l - u); }
+    if (cfg_logits) cfg_logits[i] = l;
+    l = l / temperature;
+    if (nal > 0) {
+      bool ok = false;
+      for (int a = 0; a < nal; ++a) ok |= (al[1 + a] == i);
+      if (!ok) l = -INFINITY;
+    }
+    probs[i] = l;
+    mx = fmaxf(mx, l);
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  float m2 = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m2 = fmaxf(m2, red[w]);
+  __syncthreads();
+  float s = 0.f;
+  for (int i = tid; i < V; i += blockDim.x) { const float e = expf(probs[i] - m2); probs[i] = e; s += e; }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+  for (int i = tid; i < V; i += blockDim.x) probs[i] = probs[i] / tot;
+}
+
+// after torch.multinomial: apply the forced-token schedule, record the sampled token, advance position
+__global__ void ld_decode_advance_kernel(const long* sampled, const int* forced, int* pos_ptr, long* token,
+                                         long* out_tokens, int* out_count) {
+  const int pos = *pos_ptr;
+  const int f = forced[pos + 1];   // token generated now sits at position pos + 1
+  long t = *sampled;
+  if (f >= 0) t = f;
+  else { out_tokens[*out_count] = t; *out_count = *out_count + 1; }
+  *token = t;
+  *pos_ptr = pos + 1;
+}
+
+template <int B>
+int launch_gemv_b(const GemvParams& p, hipStream_t st) {
+  dim3 grid((p.N + 3) / 4), block(256);
+  if (p.w_f32) hipLaunchKernelGGL((ld_gemv_kernel<B, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((ld_gemv_kernel<B, false>), grid, block, 0, st, p);
+  return ld_check_launch("ld_gemv");
+}
+
+}  // namespace
+
+LD_API int ld_gemv(const void* x, int64_t ldx, int32_t x_f32, const void* W, const void* W2, int32_t w_f32,
+                   const void* bias, const void* resid, int64_t ldr, void* out, int64_t ldo, int32_t out_f32,
+                   int64_t B, int64_t N, int64_t K, int32_t in_act, int32_t act, void* stream) {
+  LD_REQUIRE(x && W && out, "ld_gemv: null pointer");
+  LD_REQUIRE(B >= 1 && B <= MAXB, "ld_gemv: batch %ld not in [1,%d]", (long)B, MAXB);
+  LD_REQUIRE(K % 8 == 0 && ldx % 8 == 0, "ld_gemv: K and ldx must be multiples of 8");
+  LD_REQUIRE(!(w_f32 && W2), "ld_gemv: gated form needs bf16 weights");
+  LD_REQUIRE(!w_f32 || (x_f32 && out_f32), "ld_gemv: fp32 weights need fp32 in/out");
+  GemvParams p{};
+  p.x = x; p.W = W; p.W2 = W2; p.bias = (const bf16_t*)bias; p.resid = resid; p.out = out;
+  p.B = (int)B; p.N = (int)N; p.K = (int)K; p.ldx = ldx; p.ldo = ldo; p.ldr = ldr;
+  p.x_f32 = x_f32; p.w_f32 = w_f32; p.out_f32 = out_f32; p.in_act = in_act; p.act = act;
+  hipStream_t st = (hipStream_t)stream;
+  switch (B) {
+    case 1: return launch_gemv_b<1>(p, st);
+    case 2: return launch_gemv_b<2>(p, st);
+    case 3: return launch_gemv_b<3>(p, st);
+    default: return launch_gemv_b<4>(p, st);
+  }
+}
+
+LD_API int ld_rmsnorm_bf16(const void* x, const float* w, void* out, int64_t rows, int64_t D, float eps, void* stream) {
+  LD_REQUIRE(x && w && out && D % 8 == 0, "ld_rmsnorm_bf16: bad args");
+  hipLaunchKernelGGL(ld_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, w, (bf16_t*)out, (int)rows, (int)D, eps);
+  return ld_check_launch("ld_rmsnorm_bf16");
+}
+
+LD_API int ld_layernorm_bf16_to_f32(const void* x, int64_t ldx, const float* w, const float* b, float* out,
+                                    int64_t rows, int64_t D, float eps, void* stream) {
+  LD_REQUIRE(x && w && b && out, "ld_layernorm_bf16_to_f32: null pointer");
+  hipLaunchKernelGGL(ld_ln_f32out_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (long)ldx, w, b, out, (int)rows, (int)D, eps);
+  return ld_check_launch("ld_layernorm_bf16_to_f32");
+}
+
+LD_API int ld_llm_rope_append(const void* qkv, const float* cos_t, const float* sin_t, const int32_t* pos,
+                              void* q_out, void* k_cache, void* v_cache, int64_t B, int64_t m, int64_t H,
+                              int64_t Lmax, void* stream) {
+  LD_REQUIRE(qkv && cos_t && sin_t && pos && q_out && k_cache && v_cache, "ld_llm_rope_append: null pointer");
+  const long total = B * m * H * 64;
+  hipLaunchKernelGGL(ld_rope_append_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)qkv, cos_t, sin_t, (const int*)pos, (bf16_t*)q_out, (bf16_t*)k_cache,
+                     (bf16_t*)v_cache, (int)B, (int)m, (int)H, (int)Lmax);
+  return ld_check_launch("ld_llm_rope_append");
+}
+
+LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
+                          int64_t B, int64_t m, int64_t H, int64_t Lmax, void* stream) {
+  LD_REQUIRE(q && k_cache && v_cache && pos && out, "ld_llm_kv_attn: null pointer");
+  const size_t smem = (size_t)(Lmax + 8 + 256) * sizeof(float);
+  LD_REQUIRE(smem <= 160 * 1024, "ld_llm_kv_attn: Lmax=%ld too long for the LDS score buffer", (long)Lmax);
+  static size_t attr = 0;
+  if (smem > attr) {
+    (void)hipFuncSetAttribute((const void*)ld_kv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = smem;
+  }
+  hipLaunchKernelGGL(ld_kv_attn_kernel, dim3((unsigned)(B * H), (unsigned)m), dim3(256), smem, (hipStream_t)stream,
+                     (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, (const int*)pos,
+                     (bf16_t*)out, (int)B, (int)m, (int)H, (int)Lmax);
+  return ld_check_launch("ld_llm_kv_attn");
+}
+
+LD_API int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B, int64_t D, void* stream) {
+  LD_REQUIRE(table && token && out, "ld_llm_embed: null pointer");
+  hipLaunchKernelGGL(ld_embed_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     table, (const long*)token, (bf16_t*)out, (int)B, (int)D);
+  return ld_check_launch("ld_llm_embed");
+}
+
+LD_API int ld_llm_logits_to_probs(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided,
+                                  float scale, float temperature, const int32_t* pos, const int32_t* allowed,
+                                  int64_t allowed_stride, void* stream) {
+  LD_REQUIRE(logits && probs && V > 0, "ld_llm_logits_to_probs: bad args");
+  LD_REQUIRE(!allowed || pos, "ld_llm_logits_to_probs: allowed table needs pos");
+  hipLaunchKernelGGL(ld_logits_to_probs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, probs, cfg_logits,
+                     (int)V, guided, scale, temperature, (const int*)pos, (const int*)allowed, (int)allowed_stride);
+  return ld_check_launch("ld_llm_logits_to_probs");
+}
+
+LD_API int ld_llm_decode_advance(const int64_t* sampled, const int32_t* forced, int32_t* pos, int64_t* token,
+                                 int64_t* out_tokens, int32_t* out_count, void* stream) {
+  LD_REQUIRE(sampled && forced && pos && token && out_tokens && out_count, "ld_llm_decode_advance: null pointer");
+  hipLaunchKernelGGL(ld_decode_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const long*)sampled,
+                     (const int*)forced, (int*)pos, (long*)token, (long*)out_tokens, (int*)out_count);
+  return ld_check_launch("ld_llm_decode_advance");
+}

@@ -1,0 +1,408 @@
+// HBM-bound normalisation kernels: LayerNorm (+AdaLN modulate, text/image regions), qkv head split with
+// QK-LayerNorm or 3D RoPE and V transposition, GroupNorm statistics, fused GroupNorm/SpatialNorm + swish.
+//
+// Replaces: layer.input_layernorm/post_attention_layernorm + modulate
+// (landiff/diffusion/dit_video_concat.py:388,577-586,601-611), query/key_layernorm (:649-653), sat's
+// _transpose_for_scores; MultiheadAttention's head split + apply_rope (landiff/tokenizer/modules/blocks.py:172-180);
+// Normalize/GroupNorm + nonlinearity (vq_gan_blocks.py:29-38), SpatialNorm3D.forward + nonlinearity
+// (landiff/diffusion/vae_modules/cp_enc_dec.py:67-69,546-569).
+//
+// All of these are pure streaming passes: 16-byte coalesced loads, one wave64 per row (no LDS, no barriers)
+// for the LayerNorms, fp32 statistics, bf16 outputs rounded at the same points the reference's bf16 ops round.
+#include "ld_common.h"
+#include "../../include/landiff_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over D (D % 8 == 0, D <= 4096), optional AdaLN modulation selected per row region.
+// ---------------------------------------------------------------------------------------------
+struct LnParams {
+  const void* x; void* out;
+  const bf16_t* w; const bf16_t* b;
+  const bf16_t* mod;            // modulation vectors, or null
+  long ldx, ldo;
+  int rows, D;
+  float eps;
+  int x_f32, out_f32;
+  int rows_per_batch, text_len;
+  long mod_bstride, shift_img, scale_img, shift_txt, scale_txt;
+};
+
+template <int NC>   // chunks (of 8 elements) per lane
+__global__ __launch_bounds__(256) void ld_layernorm_kernel(LnParams p) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.rows) return;
+  const int nchunk = p.D >> 3;
+  float v[NC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      if (p.x_f32) {
+        const float* xr = (const float*)p.x + (long)r * p.ldx + c * 8;
+        const f32x4_t a = *(const f32x4_t*)xr, b4 = *(const f32x4_t*)(xr + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = b4[e]; }
+      } else {
+        const u32x4_t a = *(const u32x4_t*)((const bf16_t*)p.x + (long)r * p.ldx + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][2 * e] = bf_lo(a[e]); v[i][2 * e + 1] = bf_hi(a[e]); }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)p.D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    if (lane + 64 * i < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)p.D + p.eps);
+  const bf16_t* shift = nullptr; const bf16_t* scale = nullptr;
+  if (p.mod) {
+    const int bb = r / p.rows_per_batch;
+    const bool txt = (r - bb * p.rows_per_batch) < p.text_len;
+    shift = p.mod + bb * p.mod_bstride + (txt ? p.shift_txt : p.shift_img);
+    scale = p.mod + bb * p.mod_bstride + (txt ? p.scale_txt : p.scale_img);
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c >= nchunk) continue;
+    float y[8];
+    float wv[8], bv[8];
+    if (p.w) {
+      const u32x4_t ww = *(const u32x4_t*)(p.w + c * 8), bw = *(const u32x4_t*)(p.b + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { wv[2 * e] = bf_lo(ww[e]); wv[2 * e + 1] = bf_hi(ww[e]); bv[2 * e] = bf_lo(bw[e]); bv[2 * e + 1] = bf_hi(bw[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (v[i][e] - mean) * rstd;
+      if (p.w) t = t * wv[e] + bv[e];
+      y[e] = t;
+    }
+    if (shift) {
+      const u32x4_t sh = *(const u32x4_t*)(shift + c * 8), sc = *(const u32x4_t*)(scale + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // modulate(): x * (1 + scale) + shift, every op in bf16 as in the reference
+        const float s0 = rbf(1.0f + bf_lo(sc[e])), s1 = rbf(1.0f + bf_hi(sc[e]));
+        y[2 * e] = rbf(rbf(rbf(y[2 * e]) * s0) + bf_lo(sh[e]));
+        y[2 * e + 1] = rbf(rbf(rbf(y[2 * e + 1]) * s1) + bf_hi(sh[e]));
+      }
+    }
+    if (p.out_f32) {
+      float* o = (float*)p.out + (long)r * p.ldo + c * 8;
+      *(f32x4_t*)o = (f32x4_t){y[0], y[1], y[2], y[3]};
+      *(f32x4_t*)(o + 4) = (f32x4_t){y[4], y[5], y[6], y[7]};
+    } else {
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(y[2 * e], y[2 * e + 1]);
+      *(u32x4_t*)((bf16_t*)p.out + (long)r * p.ldo + c * 8) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// qkv [B*N][3*H*64] (thirds q|k|v) -> Q,K [B][H][Npad][64] and V^T [B][H][64][Npad].
+// mode 0: per-head LayerNorm(64) on q and k (DiT);  mode 1: interleaved-pair RoPE with a [N][32] table (TiTok).
+// One workgroup = 64 tokens x 1 head.
+// ---------------------------------------------------------------------------------------------
+struct SplitParams {
+  const bf16_t* qkv; bf16_t* Q; bf16_t* K; bf16_t* Vt;
+  const bf16_t* qw; const bf16_t* qb; const bf16_t* kw; const bf16_t* kb;
+  const float* cos_t; const float* sin_t;
+  int B, N, H, Npad, mode;
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void ld_qkv_split_kernel(SplitParams p) {
+  __shared__ bf16_t vt[64][72];     // V tile [token][d] (+pad) for the transposed write
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const long row_stride = 3L * p.H * 64;
+  // ---- q and k: 8 lanes per (token, tensor), 8 elements per lane ----
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int task = it * 256 + tid;        // 0..1023 = 64 tokens x 2 tensors x 8 lanes
+    const int sub = task & 7;
+    const int which = (task >> 3) & 1;      // 0 = q, 1 = k
+    const int tok = task >> 4;
+    const int n = n0 + tok;
+    float v[8];
+    const bool valid = n < p.N;
+    if (valid) {
+      const u32x4_t a = *(const u32x4_t*)(p.qkv + ((long)b * p.N + n) * row_stride + (long)which * p.H * 64 + h * 64 + sub * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(a[e]); v[2 * e + 1] = bf_hi(a[e]); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    if (p.mode == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      const float mean = s * (1.0f / 64.0f);
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; ss += d * d; }
+      ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+      const float rstd = rsqrtf(ss * (1.0f / 64.0f) + p.eps);
+      const bf16_t* w = which ? p.kw : p.qw;
+      const bf16_t* bb = which ? p.kb : p.qb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * bf2f(w[sub * 8 + e]) + bf2f(bb[sub * 8 + e]);
+    } else if (valid) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float c = p.cos_t[(long)n * 32 + sub * 4 + e], s = p.sin_t[(long)n * 32 + sub * 4 + e];
+        const float a0 = v[2 * e], a1 = v[2 * e + 1];
+        v[2 * e] = a0 * c - a1 * s;
+        v[2 * e + 1] = a0 * s + a1 * c;
+      }
+    }
+    if (!valid) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;     // zero rows in the padding region
+    }
+    bf16_t* dst = (which ? p.K : p.Q) + (((long)b * p.H + h) * p.Npad + n) * 64 + sub * 8;
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+    if (n < p.Npad) *(u32x4_t*)dst = o;
+  }
+  // ---- v: stage [64 tokens][64 d] in LDS, write transposed rows [d][64 tokens] ----
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int task = it * 256 + tid;        // 512 = 64 tokens x 8 chunks
+    const int sub = task & 7, tok = task >> 3;
+    const int n = n0 + tok;
+    u32x4_t a = {0u, 0u, 0u, 0u};
+    if (n < p.N) a = *(const u32x4_t*)(p.qkv + ((long)b * p.N + n) * row_stride + 2L * p.H * 64 + h * 64 + sub * 8);
+    *(u32x4_t*)(&vt[tok][sub * 8]) = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int task = it * 256 + tid;        // 512 = 64 d x 8 token-chunks
+    const int tc = task & 7, d = task >> 3;
+    bf16_t tmp[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tmp[e] = vt[tc * 8 + e][d];
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)tmp[2 * e] | ((uint32_t)tmp[2 * e + 1] << 16);
+    if (n0 + tc * 8 < p.Npad)
+      *(u32x4_t*)(p.Vt + (((long)b * p.H + h) * 64 + d) * p.Npad + n0 + tc * 8) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics over a channels-last tensor x [F][P][C]: per (frame-group f, group g) sum and sum of
+// squares, accumulated in double with one atomic pair per workgroup.  stats [F][G][2] must be zeroed.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ld_gn_stats_kernel(const bf16_t* x, double* stats, long P, int C, int G, int rows_per_block) {
+  __shared__ float red[2][64];      // per group partials (G <= 64)
+  const int f = blockIdx.y;
+  const long p0 = (long)blockIdx.x * rows_per_block;
+  const int cpg = C / G;
+  const int chunks_per_row = C >> 3;
+  const int tid = threadIdx.x;
+  if (tid < 128) red[tid >> 6][tid & 63] = 0.f;
+  __syncthreads();
+  // a thread owns one 8-channel chunk column (fixed group) and strides over rows
+  const int chunk = tid % chunks_per_row;
+  const int rlane = tid / chunks_per_row;
+  const int rstep = 256 / chunks_per_row;
+  float s = 0.f, ss = 0.f;
+  if (rlane < rstep) {
+    const long pend = min(p0 + rows_per_block, P);
+    for (long r = p0 + rlane; r < pend; r += rstep) {
+      const u32x4_t a = *(const u32x4_t*)(x + ((long)f * P + r) * C + chunk * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float lo = bf_lo(a[e]), hi = bf_hi(a[e]); s += lo + hi; ss += lo * lo + hi * hi; }
+    }
+    const int g = (chunk * 8) / cpg;       // requires cpg % 8 == 0 or 8 % cpg == 0 handled below
+    if (cpg >= 8) {
+      atomicAdd(&red[0][g], s);
+      atomicAdd(&red[1][g], ss);
+    }
+  }
+  if (cpg < 8 && rlane < rstep) {
+    // small groups (cpg in {2,4}): redo per element (rare: 64-channel tensors)
+    const long pend = min(p0 + rows_per_block, P);
+    float gs[4] = {0, 0, 0, 0}, gss[4] = {0, 0, 0, 0};
+    for (long r = p0 + rlane; r < pend; r += rstep) {
+      const bf16_t* xr = x + ((long)f * P + r) * C + chunk * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float v = bf2f(xr[e]); gs[e / cpg % 4] += v; gss[e / cpg % 4] += v * v; }
+    }
+    for (int q = 0; q < 8 / cpg; ++q) {
+      atomicAdd(&red[0][(chunk * 8) / cpg + q], gs[q]);
+      atomicAdd(&red[1][(chunk * 8) / cpg + q], gss[q]);
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    atomicAdd(&stats[((long)f * G + tid) * 2 + 0], (double)red[0][tid]);
+    atomicAdd(&stats[((long)f * G + tid) * 2 + 1], (double)red[1][tid]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Apply GroupNorm (+ optional SpatialNorm scale/shift from low-res zq convs) + optional swish and write the
+// result into the interior of a zero-bordered channels-last buffer (the conv kernel's input layout).
+//   x [F*T][H][W][C]  ->  out [F][T + tpad][H + 2*hpad][W + 2*wpad][Cout_stride]  at (t + tpad, h + hpad, w + wpad)
+// ---------------------------------------------------------------------------------------------
+struct GnApplyParams {
+  const bf16_t* x; bf16_t* out;
+  const double* stats; const bf16_t* gamma; const bf16_t* beta;
+  const bf16_t* zy; const bf16_t* zb;     // [Tz][Hz][Wz][C] or null
+  int F, T, H, W, C, G;
+  int Tz, Hz, Wz;
+  int tpad, hpad, wpad;
+  int swish;
+  float eps;
+  double inv_count;
+};
+
+__global__ __launch_bounds__(256) void ld_gn_apply_kernel(GnApplyParams p) {
+  __shared__ float s_mean[512], s_rstd[512];      // per (frame-group, group)
+  for (int i = threadIdx.x; i < p.F * p.G; i += 256) {
+    const double mean = p.stats[2 * i] * p.inv_count;
+    const double var = p.stats[2 * i + 1] * p.inv_count - mean * mean;
+    s_mean[i] = (float)mean;
+    s_rstd[i] = rsqrtf(fmaxf((float)var, 0.f) + p.eps);
+  }
+  __syncthreads();
+  const int chunks = p.C >> 3;
+  const long total = (long)p.F * p.T * p.H * p.W * chunks;
+  const int cpg = p.C / p.G;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int chunk = (int)(i % chunks);
+    long pos = i / chunks;
+    const int w = (int)(pos % p.W); pos /= p.W;
+    const int h = (int)(pos % p.H); pos /= p.H;
+    const int t = (int)(pos % p.T);
+    const int f = (int)(pos / p.T);
+    const u32x4_t a = *(const u32x4_t*)(p.x + (i / chunks) * p.C + chunk * 8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(a[e]); v[2 * e + 1] = bf_hi(a[e]); }
+    const u32x4_t gw = *(const u32x4_t*)(p.gamma + chunk * 8), bw = *(const u32x4_t*)(p.beta + chunk * 8);
+    float sy[8], sb[8];
+    if (p.zy) {
+      int tz;
+      if (p.T > 1 && (p.T & 1)) tz = (t == 0) ? 0 : 1 + (int)(((long)(t - 1) * (p.Tz - 1)) / (p.T - 1));
+      else tz = (int)(((long)t * p.Tz) / p.T);
+      const int hz = (int)(((long)h * p.Hz) / p.H), wz = (int)(((long)w * p.Wz) / p.W);
+      const long zo = (((long)tz * p.Hz + hz) * p.Wz + wz) * p.C + chunk * 8;
+      const u32x4_t yw = *(const u32x4_t*)(p.zy + zo), zw = *(const u32x4_t*)(p.zb + zo);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sy[2 * e] = bf_lo(yw[e]); sy[2 * e + 1] = bf_hi(yw[e]); sb[2 * e] = bf_lo(zw[e]); sb[2 * e + 1] = bf_hi(zw[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (chunk * 8 + e) / cpg;
+      const float mean = s_mean[f * p.G + g], rstd = s_rstd[f * p.G + g];
+      const float gm = (e & 1) ? bf_hi(gw[e >> 1]) : bf_lo(gw[e >> 1]);
+      const float bt = (e & 1) ? bf_hi(bw[e >> 1]) : bf_lo(bw[e >> 1]);
+      float y = rbf((v[e] - mean) * rstd * gm + bt);      // GroupNorm output (bf16)
+      if (p.zy) y = rbf(rbf(y * sy[e]) + sb[e]);                  // norm_f * conv_y(zq) + conv_b(zq)
+      if (p.swish) y = rbf(y * rbf(1.0f / (1.0f + __expf(-y))));  // x * sigmoid(x)
+      v[e] = y;
+    }
+    const long Tp = p.T + p.tpad, Hp = p.H + 2 * p.hpad, Wp = p.W + 2 * p.wpad;
+    const long o = ((((long)f * Tp + t + p.tpad) * Hp + h + p.hpad) * Wp + w + p.wpad) * p.C + chunk * 8;
+    u32x4_t ow;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ow[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+    *(u32x4_t*)(p.out + o) = ow;
+  }
+}
+
+}  // namespace
+
+LD_API int ld_layernorm(const void* x, int64_t ldx, int32_t x_f32, const void* w, const void* b, void* out, int64_t ldo,
+                        int32_t out_f32, int64_t rows, int64_t D, float eps, const void* mod, int64_t mod_bstride,
+                        int64_t shift_img, int64_t scale_img, int64_t shift_txt, int64_t scale_txt,
+                        int64_t rows_per_batch, int64_t text_len, void* stream) {
+  LD_REQUIRE(x && out, "ld_layernorm: null pointer");
+  LD_REQUIRE(D % 8 == 0 && D <= 4096 && D > 0, "ld_layernorm: D=%ld must be a multiple of 8 and <= 4096", (long)D);
+  LD_REQUIRE((w == nullptr) == (b == nullptr), "ld_layernorm: weight and bias go together");
+  LnParams p{};
+  p.x = x; p.out = out; p.w = (const bf16_t*)w; p.b = (const bf16_t*)b; p.mod = (const bf16_t*)mod;
+  p.ldx = ldx; p.ldo = ldo; p.rows = (int)rows; p.D = (int)D; p.eps = eps; p.x_f32 = x_f32; p.out_f32 = out_f32;
+  p.rows_per_batch = rows_per_batch > 0 ? (int)rows_per_batch : (1 << 30); p.text_len = (int)text_len;
+  p.mod_bstride = mod_bstride; p.shift_img = shift_img; p.scale_img = scale_img; p.shift_txt = shift_txt; p.scale_txt = scale_txt;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nc = (int)((D / 8 + 63) / 64);
+  switch (nc) {
+    case 1: hipLaunchKernelGGL(ld_layernorm_kernel<1>, grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL(ld_layernorm_kernel<2>, grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL(ld_layernorm_kernel<3>, grid, block, 0, st, p); break;
+    case 4: hipLaunchKernelGGL(ld_layernorm_kernel<4>, grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL(ld_layernorm_kernel<8>, grid, block, 0, st, p); break;
+  }
+  return ld_check_launch("ld_layernorm");
+}
+
+LD_API int ld_qkv_split(const void* qkv, void* Q, void* K, void* Vt, int64_t B, int64_t N, int64_t H, int64_t Npad,
+                        int32_t mode, const void* q_w, const void* q_b, const void* k_w, const void* k_b, float eps,
+                        const float* cos_t, const float* sin_t, void* stream) {
+  LD_REQUIRE(qkv && Q && K && Vt, "ld_qkv_split: null pointer");
+  LD_REQUIRE(Npad % 64 == 0 && Npad >= N, "ld_qkv_split: Npad must be a multiple of 64 and >= N");
+  LD_REQUIRE(mode == 0 ? (q_w && q_b && k_w && k_b) : (cos_t && sin_t), "ld_qkv_split: missing LN weights / RoPE table");
+  SplitParams p{};
+  p.qkv = (const bf16_t*)qkv; p.Q = (bf16_t*)Q; p.K = (bf16_t*)K; p.Vt = (bf16_t*)Vt;
+  p.qw = (const bf16_t*)q_w; p.qb = (const bf16_t*)q_b; p.kw = (const bf16_t*)k_w; p.kb = (const bf16_t*)k_b;
+  p.cos_t = cos_t; p.sin_t = sin_t; p.B = (int)B; p.N = (int)N; p.H = (int)H; p.Npad = (int)Npad; p.mode = mode; p.eps = eps;
+  dim3 grid((unsigned)(Npad / 64), (unsigned)H, (unsigned)B), block(256);
+  hipLaunchKernelGGL(ld_qkv_split_kernel, grid, block, 0, (hipStream_t)stream, p);
+  return ld_check_launch("ld_qkv_split");
+}
+
+LD_API int ld_groupnorm_stats(const void* x, double* stats, int64_t F, int64_t P, int64_t C, int64_t G, void* stream) {
+  LD_REQUIRE(x && stats, "ld_groupnorm_stats: null pointer");
+  LD_REQUIRE(C % 8 == 0 && C / 8 <= 256 && G <= 64 && C % G == 0, "ld_groupnorm_stats: unsupported C=%ld G=%ld", (long)C, (long)G);
+  const int cpg = (int)(C / G);
+  LD_REQUIRE(cpg % 8 == 0 || 8 % cpg == 0, "ld_groupnorm_stats: channels per group %d unsupported", cpg);
+  const int rows_per_block = 512;
+  dim3 grid((unsigned)((P + rows_per_block - 1) / rows_per_block), (unsigned)F), block(256);
+  hipLaunchKernelGGL(ld_gn_stats_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, stats, (long)P, (int)C, (int)G, rows_per_block);
+  return ld_check_launch("ld_groupnorm_stats");
+}
+
+LD_API int ld_groupnorm_apply(const void* x, void* out_padded, const double* stats, const void* gamma, const void* beta,
+                              const void* zy, const void* zb, int64_t F, int64_t T, int64_t H, int64_t W, int64_t C,
+                              int64_t G, int64_t Tz, int64_t Hz, int64_t Wz, int64_t tpad, int64_t hpad, int64_t wpad,
+                              int32_t swish, float eps, void* stream) {
+  LD_REQUIRE(x && out_padded && stats && gamma && beta, "ld_groupnorm_apply: null pointer");
+  LD_REQUIRE((zy == nullptr) == (zb == nullptr), "ld_groupnorm_apply: zy and zb go together");
+  LD_REQUIRE(C % 8 == 0 && C % G == 0, "ld_groupnorm_apply: bad channel count");
+  LD_REQUIRE(F * G <= 512, "ld_groupnorm_apply: F*G=%ld exceeds 512", (long)(F * G));
+  GnApplyParams p{};
+  p.x = (const bf16_t*)x; p.out = (bf16_t*)out_padded; p.stats = stats; p.gamma = (const bf16_t*)gamma; p.beta = (const bf16_t*)beta;
+  p.zy = (const bf16_t*)zy; p.zb = (const bf16_t*)zb;
+  p.F = (int)F; p.T = (int)T; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.G = (int)G;
+  p.Tz = (int)Tz; p.Hz = (int)Hz; p.Wz = (int)Wz; p.tpad = (int)tpad; p.hpad = (int)hpad; p.wpad = (int)wpad;
+  p.swish = swish; p.eps = eps;
+  p.inv_count = 1.0 / ((double)T * H * W * (C / G));
+  const long total = F * T * H * W * (C / 8);
+  const long blocks = (total + 255) / 256;
+  dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
+  hipLaunchKernelGGL(ld_gn_apply_kernel, grid, block, 0, (hipStream_t)stream, p);
+  return ld_check_launch("ld_groupnorm_apply");
+}

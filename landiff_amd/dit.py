@@ -1,0 +1,174 @@
+"""Control + main diffusion transformer on MI355X (host orchestration over the HIP kernels).
+
+Mirrors ControlDiffWarp.forward -> ControlDiffusionTransformer.forward / DiffusionTransformer.forward
+(landiff/diffusion/dit_video_concat.py:872-1027,1196-1200) with the AdaLN layer of :540-629 / :1260-1372 and
+sat's transformer internals as recorded in SURVEY.md 8c.  Every tensor op below is a kernel from
+liblandiff_hip.so; torch only owns the buffers.
+
+HBM layout: the joint sequence is a row-major [B*(text+T*h*w)][hidden] bf16 matrix (B = 2: uncond, cond);
+q/k live as [B][H][Npad][64], v transposed as [B][H][64][Npad]; all workspaces are allocated once.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .config import DiTConfig
+
+BF = torch.bfloat16
+
+
+def _dev(t, device, dtype=BF):
+    return t.detach().to(device=device, dtype=dtype).contiguous()
+
+
+class _Branch:
+    """Packed weights of one DiffusionTransformer (control or main)."""
+
+    def __init__(self, sd: dict, cfg: DiTConfig, control: bool, device):
+        d = cfg.hidden
+        self.control = control
+        self.L = cfg.layers_control if control else cfg.layers_main
+        g = lambda k: _dev(sd[k], device)
+        self.te0_w, self.te0_b = g("time_embed.0.weight"), g("time_embed.0.bias")
+        self.te2_w, self.te2_b = g("time_embed.2.weight"), g("time_embed.2.bias")
+        self.pos = g("mixins.pos_embed.pos_embedding")[0]                       # [seq, d]
+        self.patch_w = g("mixins.patch_embed.proj.weight").reshape(d, -1).contiguous()   # [d, C*p*p]
+        self.patch_b = g("mixins.patch_embed.proj.bias")
+        self.text_w, self.text_b = g("mixins.patch_embed.text_proj.weight"), g("mixins.patch_embed.text_proj.bias")
+        self.layers = []
+        for i in range(self.L):
+            p = f"transformer.layers.{i}."
+            a = "mixins.adaln_layer."
+            lw = dict(
+                ln1_w=g(p + "input_layernorm.weight"), ln1_b=g(p + "input_layernorm.bias"),
+                qkv_w=g(p + "attention.query_key_value.weight"), qkv_b=g(p + "attention.query_key_value.bias"),
+                dense_w=g(p + "attention.dense.weight"), dense_b=g(p + "attention.dense.bias"),
+                ln2_w=g(p + "post_attention_layernorm.weight"), ln2_b=g(p + "post_attention_layernorm.bias"),
+                h4_w=g(p + "mlp.dense_h_to_4h.weight"), h4_b=g(p + "mlp.dense_h_to_4h.bias"),
+                h1_w=g(p + "mlp.dense_4h_to_h.weight"), h1_b=g(p + "mlp.dense_4h_to_h.bias"),
+                ada_w=g(a + f"adaLN_modulations.{i}.1.weight"), ada_b=g(a + f"adaLN_modulations.{i}.1.bias"),
+                qln=(g(a + f"query_layernorm_list.{i}.weight"), g(a + f"query_layernorm_list.{i}.bias"),
+                     g(a + f"key_layernorm_list.{i}.weight"), g(a + f"key_layernorm_list.{i}.bias")),
+            )
+            if control:
+                lw["zero_w"] = g(a + f"zero_linears.{i}.weight")
+            self.layers.append(lw)
+        if not control:
+            f = "mixins.final_layer."
+            self.fln_w, self.fln_b = g("transformer.final_layernorm.weight"), g("transformer.final_layernorm.bias")
+            self.nf_w, self.nf_b = g(f + "norm_final.weight"), g(f + "norm_final.bias")
+            self.lin_w, self.lin_b = g(f + "linear.weight"), g(f + "linear.bias")
+            self.fada_w, self.fada_b = g(f + "adaLN_modulation.1.weight"), g(f + "adaLN_modulation.1.bias")
+
+
+class ControlDiTRunner:
+    """Evaluates the CFG pair (uncond, cond) of the control+main DiT for one sampler step."""
+
+    B = 2
+
+    def __init__(self, main_sd: dict, control_sd: dict, cfg: DiTConfig, device):
+        self.cfg, self.dev = cfg, device
+        self.main = _Branch(main_sd, cfg, False, device)
+        self.ctrl = _Branch(control_sd, cfg, True, device)
+        c, B = cfg, self.B
+        d, N = c.hidden, c.seq_len
+        M = B * N
+        self.N, self.M = N, M
+        self.Npad = (N + 127) // 128 * 128
+        e = lambda *s, dt=BF: torch.empty(*s, device=device, dtype=dt)
+        self.h = e(M, d)                        # main residual stream
+        self.hc = e(M, d)                       # control working stream
+        self.ctrl_out = [e(M, d) for _ in range(c.layers_control)]
+        self.ln = e(M, d)
+        self.qkv = e(M, 3 * d)
+        self.q = torch.zeros(B, c.heads, self.Npad, 64, device=device, dtype=BF)
+        self.k = torch.zeros_like(self.q)
+        self.vt = torch.zeros(B, c.heads, 64, self.Npad, device=device, dtype=BF)
+        self.attn = e(B, N, d)
+        self.mlp = e(M, 4 * d)
+        self.patches = e(c.n_img, c.in_channels * c.patch * c.patch)
+        self.temb = e(B, d)
+        self.emb_h = e(B, c.time_embed_dim)
+        self.emb = e(B, c.time_embed_dim)
+        self.ada = e(B, 12 * d)
+        self.fada = e(B, 2 * d)
+        self.lin = e(B, c.n_img, c.patch * c.patch * c.out_channels)
+        self.tvec = e(B, dt=torch.float32)
+        self.txt_main = e(B, c.text_len, d)
+        self.txt_ctrl = e(B, c.text_len, d)
+        self.sem = None                         # [T, C, H, W] bf16, set per video
+
+    # ---- per-video setup -------------------------------------------------------------------
+    def set_condition(self, context: torch.Tensor, semantic_feature: torch.Tensor):
+        """context [1, text_len, text_dim] (T5 states of the prompt; the uncond branch uses zeros,
+        dif_infer.py:214-218), semantic_feature [T, C, H, W] bf16 (SemanticCond output, cached per video)."""
+        c = self.cfg
+        ctx = torch.zeros(self.B, c.text_len, c.text_dim, device=self.dev, dtype=BF)
+        ctx[1] = context.to(self.dev, BF)[0]
+        for br, dst in ((self.main, self.txt_main), (self.ctrl, self.txt_ctrl)):
+            for b in range(self.B):   # text_proj + position rows (zero in the shipped table, added all the same)
+                ops.gemm(ctx[b], br.text_w, out=dst[b], bias=br.text_b, add2=br.pos[: c.text_len])
+        self.sem = semantic_feature.to(self.dev, BF).contiguous()
+
+    # ---- pieces ----------------------------------------------------------------------------
+    def _time_emb(self, br: _Branch, timestep: float):
+        self.tvec.fill_(float(timestep))
+        ops.timestep_embedding(self.tvec, self.temb)
+        ops.gemv(self.temb, br.te0_w, self.emb_h, bias=br.te0_b)
+        ops.gemv(self.emb_h, br.te2_w, self.emb, bias=br.te2_b, in_act="silu")
+
+    def _embed(self, br: _Branch, x: torch.Tensor, h: torch.Tensor, txt: torch.Tensor, sem):
+        c = self.cfg
+        ops.patchify(x, sem, self.patches, c.patch)
+        hv = h.view(self.B, self.N, c.hidden)
+        for b in range(self.B):      # the image half is identical for uncond/cond; text rows differ
+            ops.gemm(self.patches, br.patch_w, out=hv[b, c.text_len:], bias=br.patch_b, add2=br.pos[c.text_len:])
+            hv[b, :c.text_len].copy_(txt[b])
+
+    def _layer(self, br: _Branch, i: int, h_in: torch.Tensor, h_out: torch.Tensor, control_add=None):
+        c, lw = self.cfg, br.layers[i]
+        d, N = c.hidden, self.N
+        mod = dict(mod=self.ada, mod_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
+        ops.gemv(self.emb, lw["ada_w"], self.ada, bias=lw["ada_b"], in_act="silu")
+        ops.layernorm(h_in, lw["ln1_w"], lw["ln1_b"], self.ln, c.block_ln_eps, shift_img=0, scale_img=d,
+                      shift_txt=6 * d, scale_txt=7 * d, **mod)
+        ops.gemm(self.ln, lw["qkv_w"], out=self.qkv, bias=lw["qkv_b"])
+        ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
+        ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5)
+        gate = dict(gate=self.ada, gate_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
+        ops.gemm(self.attn.view(-1, d), lw["dense_w"], out=h_out, bias=lw["dense_b"], resid=h_in,
+                 gate_off_img=2 * d, gate_off_txt=8 * d, **gate)
+        ops.layernorm(h_out, lw["ln2_w"], lw["ln2_b"], self.ln, c.block_ln_eps, shift_img=3 * d, scale_img=4 * d,
+                      shift_txt=9 * d, scale_txt=10 * d, **mod)
+        ops.gemm(self.ln, lw["h4_w"], out=self.mlp, bias=lw["h4_b"], act="gelu_tanh")
+        ops.gemm(self.mlp, lw["h1_w"], out=h_out, bias=lw["h1_b"], resid=h_out, gate_off_img=5 * d,
+                 gate_off_txt=11 * d, add2=control_add, **gate)
+
+    # ---- one denoiser evaluation -----------------------------------------------------------
+    def step(self, x: torch.Tensor, timestep: int, c_out: float, c_skip: float, cfg_scale: float, out: torch.Tensor):
+        """x, out: [1, T, C, H, W] fp32.  out = CFG(denoised_uncond, denoised_cond)."""
+        c = self.cfg
+        # control branch: layer l+1 consumes zero_linear_l(layer_l(.))
+        self._time_emb(self.ctrl, timestep)
+        self._embed(self.ctrl, x, self.hc, self.txt_ctrl, self.sem)
+        h_in = self.hc
+        for i in range(c.layers_control):
+            self._layer(self.ctrl, i, h_in, self.hc)
+            ops.gemm(self.hc, self.ctrl.layers[i]["zero_w"], out=self.ctrl_out[i])
+            h_in = self.ctrl_out[i]
+        # main branch
+        self._time_emb(self.main, timestep)
+        self._embed(self.main, x, self.h, self.txt_main, None)
+        for i in range(c.layers_main):
+            self._layer(self.main, i, self.h, self.h, self.ctrl_out[i] if i < c.layers_control else None)
+        m, d, N = self.main, c.hidden, self.N
+        ops.layernorm(self.h, m.fln_w, m.fln_b, self.ln, c.block_ln_eps)
+        ops.gemv(self.emb, m.fada_w, self.fada, bias=m.fada_b, in_act="silu")
+        ops.layernorm(self.ln, m.nf_w, m.nf_b, self.ln, c.final_ln_eps, mod=self.fada, mod_bstride=2 * d, shift_img=0,
+                      scale_img=d, shift_txt=0, scale_txt=d, rows_per_batch=N, text_len=0)
+        lnv = self.ln.view(self.B, N, d)
+        for b in range(self.B):
+            ops.gemm(lnv[b, c.text_len:], m.lin_w, out=self.lin[b], bias=m.lin_b)
+        ops.unpatchify_cfg(self.lin, x, out, c.patch, c_out, c_skip, cfg_scale)
+        return out

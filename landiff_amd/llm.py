@@ -1,0 +1,259 @@
+"""Autoregressive semantic-token decode on MI355X.
+
+Mirrors Semantic1DLM.tokenize / .sample (landiff/llm/models/lm_model.py:175-516), GPT.sample
+(landiff/llm/models/transformer.py:91-119), LlamaTransformerBlock with the KV-cache path
+(landiff/llm/modules/transformer_blocks.py:128-236), TextCond / MicroConditioner
+(landiff/llm/modules/conditioner.py:90-170,230-323) and Rope1DPosEmb (landiff/modules/pos_emb.py:73-123).
+
+What changes is mechanism only: weights are cast to bf16 once (the reference re-casts 2 B parameters every
+forward under autocast), the KV cache is preallocated in HBM and appended in place, position / current token /
+forced-token schedule live in device memory, and the per-token step is captured in a HIP graph and replayed.
+torch.multinomial stays on PyTorch-ROCm so the RNG stream is the reference's (one draw per step, forced or not).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .config import LLMConfig
+
+BF = torch.bfloat16
+
+
+def forced_token_schedule(cfg: LLMConfig, S: int, num_frames: int):
+    """Position bookkeeping of lm_model.py:323-396 (END tokens enabled): returns (full_len, forced {pos: id},
+    restricted {pos: [ids]}, n_visual).  S is the position of the first START_OF_IFrame."""
+    I, P, seg, stride = cfg.iframe_len, cfg.pframe_len, cfg.segment_length, cfg.segment_stride
+    code_len = 0
+    for off in range(0, num_frames, stride):
+        fl = min(off + seg, num_frames) - off
+        code_len += I + (fl - 1) * P + 2 * fl
+    full_len = S + code_len + 1
+    block = I + (seg - 1) * P + 2 * seg
+    start_i, end_i, start_p, end_p, eos_ok = set(), set(), set(), set(), set()
+    for index in range(S, full_len - 1, block):          # one block per segment
+        start_i.add(index)
+        pos = index + 1 + I                               # END_OF_IFrame slot
+        end_i.add(pos)
+        pos += 1
+        if index > S:
+            eos_ok.add(pos)
+        p_end = min(full_len - 1, pos - 1 + P * (seg - 1) + 2 * (seg - 1))
+        for j in range(pos, p_end, P + 2):                # START_P, P tokens, END_P
+            start_p.add(j)
+            end_p.add(j + P + 1)
+            if index > S:
+                eos_ok.add(j + P + 2)
+    forced, restricted = {}, {}
+    for i in range(S + 1, full_len):
+        allowed = [t for t, st in ((cfg.START_I, start_i), (cfg.START_P, start_p), (cfg.EOS, eos_ok)) if i in st]
+        if allowed:
+            restricted[i] = allowed
+        for t, st in ((cfg.START_I, start_i), (cfg.END_I, end_i), (cfg.START_P, start_p), (cfg.END_P, end_p)):
+            if i in st:
+                forced[i] = t
+                break
+        else:
+            if i == full_len - 1:
+                forced[i] = cfg.EOS
+    n_visual = (full_len - S - 1) - len(forced)
+    return full_len, forced, restricted, n_visual
+
+
+class LLMRunner:
+    B = 2   # (cond, uncond)
+
+    def __init__(self, sd: dict, cfg: LLMConfig, device, max_text: int = 512, max_frames: int = 13):
+        self.cfg, self.dev = cfg, device
+        c = cfg
+        g = lambda k, dt=BF: sd[k].detach().to(device=device, dtype=dt).contiguous()
+        self.blocks = []
+        for i in range(c.num_layers):
+            p = f"transformer.blocks.{i}."
+            self.blocks.append(dict(n0=g(p + "norm0.weight", torch.float32), n1=g(p + "norm1.weight", torch.float32),
+                                    wqkv=g(p + "wqkv.weight"), wo=g(p + "wo.weight"), w1=g(p + "mlp.w1.weight"),
+                                    w3=g(p + "mlp.w3.weight"), w2=g(p + "mlp.w2.weight")))
+        self.ln_w, self.ln_b = g("transformer.layer_norm.weight", torch.float32), g("transformer.layer_norm.bias", torch.float32)
+        self.head = g("transformer.head.weight", torch.float32)
+        self.emb = g("visual_embedding_model.tok_emb_code.weight", torch.float32)
+        self.fc0 = (g("cond_model.embeddings.fc0.weight"), g("cond_model.embeddings.fc0.bias"))
+        self.fc1 = (g("cond_model.embeddings.fc1.weight"), g("cond_model.embeddings.fc1.bias"))
+        self.null_text = g("cond_model.null_text_embedding")
+        self.micro = {k: (g(f"micro_condition.mlps.{k}.0.weight"), g(f"micro_condition.mlps.{k}.0.bias"),
+                          g(f"micro_condition.mlps.{k}.2.weight"), g(f"micro_condition.mlps.{k}.2.bias"))
+                      for k in ("frames", "motion_score")}
+        # RoPE table (pos_emb.py:49-70)
+        n_seg = -(-max_frames // c.segment_stride)
+        self.Lmax = max_text + 4 + n_seg * (c.iframe_len + (c.segment_length - 1) * c.pframe_len + 2 * c.segment_length) + 2
+        freqs = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2)[: c.head_dim // 2].float() / c.head_dim))
+        ang = torch.outer(torch.arange(self.Lmax).float(), freqs).float()
+        cis = torch.polar(torch.ones_like(ang), ang)
+        self.cos, self.sin = cis.real.contiguous().to(device), cis.imag.contiguous().to(device)
+        # state in HBM
+        B, H, D = self.B, c.heads, c.head_dim
+        self.kc = [torch.zeros(B, self.Lmax, H, D, device=device, dtype=BF) for _ in range(c.num_layers)]
+        self.vc = [torch.zeros(B, self.Lmax, H, D, device=device, dtype=BF) for _ in range(c.num_layers)]
+        self.pos = torch.zeros(1, device=device, dtype=torch.int32)
+        self.pos0 = torch.zeros(1, device=device, dtype=torch.int32)
+        self.token = torch.zeros(1, device=device, dtype=torch.int64)
+        self.sampled = torch.zeros(1, 1, device=device, dtype=torch.int64)
+        self.out_tokens = torch.zeros(self.Lmax, device=device, dtype=torch.int64)
+        self.out_count = torch.zeros(1, device=device, dtype=torch.int32)
+        self.forced = torch.full((self.Lmax + 2,), -1, device=device, dtype=torch.int32)
+        self.allowed = torch.zeros(self.Lmax + 2, 4, device=device, dtype=torch.int32)
+        e = lambda *s, dt=BF: torch.empty(*s, device=device, dtype=dt)
+        self.x = e(B, c.hidden)
+        self.xn = e(B, c.hidden)
+        self.qkv = e(B, 3 * c.hidden)
+        self.qr = e(B, c.hidden)
+        self.att = e(B, c.hidden)
+        self.gate = e(B, c.mlp)
+        self.lnf = e(B, c.hidden, dt=torch.float32)
+        self.logits = e(B, c.vocab, dt=torch.float32)
+        self.probs = e(1, c.vocab, dt=torch.float32)
+        self.cfg_logits = e(1, c.vocab, dt=torch.float32)
+        self._graph = None
+
+    # ---- conditioning ------------------------------------------------------------------------
+    def _micro_cond(self, frames: float, motion_score: float):
+        c, dev = self.cfg, self.dev
+        out = torch.empty(2, c.hidden, device=dev, dtype=BF)
+        t = torch.empty(1, device=dev, dtype=torch.float32)
+        te = torch.empty(1, c.freq_dim, device=dev, dtype=BF)
+        hid = torch.empty(1, c.micro_hidden, device=dev, dtype=BF)
+        for r, (key, val) in enumerate((("frames", frames), ("motion_score", motion_score))):
+            w0, b0, w2, b2 = self.micro[key]
+            t.fill_(float(val))
+            ops.timestep_embedding(t, te)
+            ops.gemv(te, w0, hid, bias=b0)
+            ops.gemv(hid, w2, out[r:r + 1], bias=b2, in_act="silu")
+        return out
+
+    def prefix_features(self, text_emb: torch.Tensor, frames: float, motion_score: float):
+        """[BOS][frames][motion][text x n][START_I] for (cond, uncond) -> bf16 [2, n+4, hidden]."""
+        c, dev = self.cfg, self.dev
+        n = text_emb.shape[0]
+        t = text_emb.to(dev, BF).contiguous()
+        h = ops.gemm(t, self.fc0[0], bias=self.fc0[1], act="gelu_tanh")
+        cond = ops.gemm(h, self.fc1[0], bias=self.fc1[1])
+        micro = self._micro_cond(frames, motion_score)
+        feats = torch.empty(2, n + 4, c.hidden, device=dev, dtype=BF)
+        feats[:, 0] = self.emb[c.BOS].to(BF)
+        feats[:, 1:3] = micro
+        feats[0, 3:3 + n] = cond
+        feats[1, 3:3 + n] = self.null_text
+        feats[:, 3 + n] = self.emb[c.START_I].to(BF)
+        return feats
+
+    # ---- transformer ---------------------------------------------------------------------------
+    def _prefill(self, feats: torch.Tensor):
+        c = self.cfg
+        B, m, d = feats.shape
+        M = B * m
+        x = feats.reshape(M, d).contiguous()
+        xn = torch.empty_like(x)
+        qkv = torch.empty(M, 3 * d, device=self.dev, dtype=BF)
+        qr = torch.empty(M, d, device=self.dev, dtype=BF)
+        att = torch.empty(M, d, device=self.dev, dtype=BF)
+        h3 = torch.empty(M, c.mlp, device=self.dev, dtype=BF)
+        gate = torch.empty(M, c.mlp, device=self.dev, dtype=BF)
+        self.pos0.zero_()
+        for i, w in enumerate(self.blocks):
+            ops.rmsnorm(x, w["n0"], xn, c.rms_eps)
+            ops.gemm(xn, w["wqkv"], out=qkv)
+            ops.llm_rope_append(qkv, self.cos, self.sin, self.pos0, qr, self.kc[i], self.vc[i], B, m, c.heads, self.Lmax)
+            ops.llm_kv_attn(qr, self.kc[i], self.vc[i], self.pos0, att, B, m, c.heads, self.Lmax)
+            ops.gemm(att, w["wo"], out=x, resid=x)
+            ops.rmsnorm(x, w["n1"], xn, c.rms_eps)
+            ops.gemm(xn, w["w3"], out=h3)
+            ops.gemm(xn, w["w1"], out=gate, act="gelu_tanh", mul=h3)
+            ops.gemm(gate, w["w2"], out=x, resid=x)
+        last = x.view(B, m, d)[:, -1]                       # rows (b, m-1), stride m*d
+        ops.layernorm_bf16_to_f32(last, self.ln_w, self.ln_b, self.lnf, c.ln_eps)
+        ops.gemv(self.lnf, self.head, self.logits)
+
+    def _decode_forward(self):
+        """One token: embedding of *token at position *pos -> logits [2, V] (all sizes static: graph-capturable)."""
+        c, B = self.cfg, self.B
+        ops.llm_embed(self.emb, self.token, self.x)
+        for i, w in enumerate(self.blocks):
+            ops.rmsnorm(self.x, w["n0"], self.xn, c.rms_eps)
+            ops.gemv(self.xn, w["wqkv"], self.qkv)
+            ops.llm_rope_append(self.qkv, self.cos, self.sin, self.pos, self.qr, self.kc[i], self.vc[i], B, 1, c.heads, self.Lmax)
+            ops.llm_kv_attn(self.qr, self.kc[i], self.vc[i], self.pos, self.att, B, 1, c.heads, self.Lmax)
+            ops.gemv(self.att, w["wo"], self.x, resid=self.x)
+            ops.rmsnorm(self.x, w["n1"], self.xn, c.rms_eps)
+            ops.gemv(self.xn, w["w1"], self.gate, w2=w["w3"], act="gelu_tanh")
+            ops.gemv(self.gate, w["w2"], self.x, resid=self.x)
+        ops.layernorm_bf16_to_f32(self.x, self.ln_w, self.ln_b, self.lnf, c.ln_eps)
+        ops.gemv(self.lnf, self.head, self.logits)
+
+    def _sample_and_advance(self, guided, scale, temperature, generator):
+        ops.llm_logits_to_probs(self.logits, self.probs, self.cfg_logits, guided, scale, temperature, self.pos, self.allowed)
+        torch.multinomial(self.probs, num_samples=1, generator=generator, out=self.sampled)
+        ops.llm_decode_advance(self.sampled, self.forced, self.pos, self.token, self.out_tokens, self.out_count)
+
+    # ---- decode loop -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, text_emb: torch.Tensor, *, motion_score: float = 0.1, num_frames: int = 13, guidance_scale: float = 7.5,
+               temperature: float = 1.0, seed: int | None = None, generator=None, use_graph: bool = True,
+               teacher_fed=None, logits_log=None) -> torch.Tensor:
+        """Returns the clamped visual token ids, int64 [n_visual] on the device (lm_model.py:509-516).
+        top_k / top_p (off by default in the reference CLI) are not implemented on this path."""
+        c, dev = self.cfg, self.dev
+        guided = guidance_scale > 0 and guidance_scale != 1
+        assert guided, "the shipped pipeline always runs with CFG (cfg=7.5); unguided decode is not implemented"
+        feats = self.prefix_features(text_emb, float(num_frames), motion_score)
+        S = feats.shape[1] - 1
+        full_len, forced, restricted, n_visual = forced_token_schedule(c, S, num_frames)
+        assert full_len <= self.Lmax
+        ft = torch.full((self.Lmax + 2,), -1, dtype=torch.int32)
+        al = torch.zeros(self.Lmax + 2, 4, dtype=torch.int32)
+        for p, t in forced.items():
+            ft[p] = t
+        for p, ids in restricted.items():
+            al[p, 0] = len(ids)
+            al[p, 1:1 + len(ids)] = torch.tensor(ids, dtype=torch.int32)
+        self.forced.copy_(ft); self.allowed.copy_(al)
+        self.out_count.zero_()
+        if generator is None and seed:
+            generator = torch.Generator(device=dev)
+            generator.manual_seed(seed)                     # lm_model.py:398-402
+        self._prefill(feats)
+        self.pos.fill_(S)
+        self._sample_and_advance(guided, guidance_scale, temperature, generator)
+        if logits_log is not None:
+            logits_log.append(self.cfg_logits.clone())
+        steps = full_len - (S + 1) - 1
+        debug = teacher_fed is not None or logits_log is not None
+        graph = None
+        if use_graph and not debug and steps > 4:
+            graph = self._capture(guided, guidance_scale, temperature, generator)
+        for it in range(steps):
+            if teacher_fed is not None:
+                self.token.copy_(teacher_fed[it].reshape(1))
+            if graph is not None:
+                graph.replay()
+            else:
+                self._decode_forward()
+                self._sample_and_advance(guided, guidance_scale, temperature, generator)
+            if logits_log is not None:
+                logits_log.append(self.cfg_logits.clone())
+        assert int(self.out_count.item()) == n_visual, (int(self.out_count.item()), n_visual)
+        return self.out_tokens[:n_visual].clamp(0, c.visual_vocab - 1)
+
+    def _capture(self, guided, scale, temperature, generator):
+        """Capture one decode step (forward + sampling + advance) into a HIP graph."""
+        g = torch.cuda.CUDAGraph()
+        if generator is not None:
+            g.register_generator_state(generator)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                self._decode_forward()
+                self._sample_and_advance(guided, scale, temperature, generator)
+        torch.cuda.current_stream().wait_stream(s)
+        return g

@@ -119,3 +119,140 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tens
                                _ptr(fid_q), _ptr(fid_k), _ptr(kt_min), _ptr(kt_max), _stream()),
           "ld_attn_fwd_bf16")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# small-batch / LLM kernels
+# ------------------------------------------------------------------------------------------------
+def gemv(x, w, out, *, w2=None, bias=None, resid=None, in_act=None, act=None):
+    """out[B,N] = epi(x[B,K] @ w[N,K]^T) for B <= 4 (weight streaming)."""
+    B, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and out.shape == (B, N) and x.stride(1) == 1 and out.stride(1) == 1 and w.is_contiguous()
+    w_f32 = w.dtype == torch.float32
+    lib = _lib.load()
+    check(lib.ld_gemv(_ptr(x), x.stride(0), int(x.dtype == torch.float32), _ptr(w), _ptr(w2), int(w_f32), _ptr(bias),
+                      _ptr(resid), resid.stride(0) if resid is not None else 0, _ptr(out), out.stride(0),
+                      int(out.dtype == torch.float32), B, N, K, ACT[in_act], ACT[act], _stream()), "ld_gemv")
+    return out
+
+
+def rmsnorm(x, w, out, eps):
+    rows, D = x.shape
+    _bf16(x, "x")
+    assert w.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    check(_lib.load().ld_rmsnorm_bf16(_ptr(x), _ptr(w), _ptr(out), rows, D, float(eps), _stream()), "ld_rmsnorm_bf16")
+    return out
+
+
+def layernorm_bf16_to_f32(x, w, b, out, eps):
+    rows, D = x.shape
+    check(_lib.load().ld_layernorm_bf16_to_f32(_ptr(x), x.stride(0), _ptr(w), _ptr(b), _ptr(out), rows, D, float(eps),
+                                               _stream()), "ld_layernorm_bf16_to_f32")
+    return out
+
+
+def llm_rope_append(qkv, cos_t, sin_t, pos, q_out, k_cache, v_cache, B, m, H, Lmax):
+    check(_lib.load().ld_llm_rope_append(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), _ptr(pos), _ptr(q_out), _ptr(k_cache),
+                                         _ptr(v_cache), B, m, H, Lmax, _stream()), "ld_llm_rope_append")
+
+
+def llm_kv_attn(q, k_cache, v_cache, pos, out, B, m, H, Lmax):
+    check(_lib.load().ld_llm_kv_attn(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(pos), _ptr(out), B, m, H, Lmax,
+                                     _stream()), "ld_llm_kv_attn")
+
+
+def llm_embed(table, token, out):
+    B, D = out.shape
+    check(_lib.load().ld_llm_embed(_ptr(table), _ptr(token), _ptr(out), B, D, _stream()), "ld_llm_embed")
+
+
+def llm_logits_to_probs(logits, probs, cfg_logits, guided, scale, temperature, pos=None, allowed=None):
+    V = probs.shape[-1]
+    check(_lib.load().ld_llm_logits_to_probs(_ptr(logits), _ptr(probs), _ptr(cfg_logits), V, int(guided), float(scale),
+                                             float(temperature), _ptr(pos), _ptr(allowed),
+                                             allowed.stride(0) if allowed is not None else 0, _stream()),
+          "ld_llm_logits_to_probs")
+
+
+def llm_decode_advance(sampled, forced, pos, token, out_tokens, out_count):
+    check(_lib.load().ld_llm_decode_advance(_ptr(sampled), _ptr(forced), _ptr(pos), _ptr(token), _ptr(out_tokens),
+                                            _ptr(out_count), _stream()), "ld_llm_decode_advance")
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------------
+def layernorm(x, w, b, out, eps, *, mod=None, mod_bstride=0, shift_img=0, scale_img=0, shift_txt=0, scale_txt=0,
+              rows_per_batch=0, text_len=0):
+    rows, D = x.shape
+    assert x.stride(1) == 1 and out.stride(1) == 1
+    check(_lib.load().ld_layernorm(_ptr(x), x.stride(0), int(x.dtype == torch.float32), _ptr(w), _ptr(b), _ptr(out),
+                                   out.stride(0), int(out.dtype == torch.float32), rows, D, float(eps), _ptr(mod),
+                                   mod_bstride, shift_img, scale_img, shift_txt, scale_txt, rows_per_batch, text_len,
+                                   _stream()), "ld_layernorm")
+    return out
+
+
+def qkv_split(qkv, q, k, vt, B, N, H, Npad, *, ln=None, rope=None, eps=1e-6):
+    """ln = (q_w, q_b, k_w, k_b) for the DiT QK-LayerNorm, or rope = (cos, sin) [N,32] fp32 for TiTok."""
+    mode = 0 if ln is not None else 1
+    lw = ln if ln is not None else (None,) * 4
+    rp = rope if rope is not None else (None, None)
+    check(_lib.load().ld_qkv_split(_ptr(qkv), _ptr(q), _ptr(k), _ptr(vt), B, N, H, Npad, mode, _ptr(lw[0]), _ptr(lw[1]),
+                                   _ptr(lw[2]), _ptr(lw[3]), float(eps), _ptr(rp[0]), _ptr(rp[1]), _stream()),
+          "ld_qkv_split")
+
+
+def groupnorm_stats(x, stats, F, P, C, G):
+    assert stats.dtype == torch.float64
+    stats.zero_()
+    check(_lib.load().ld_groupnorm_stats(_ptr(x), _ptr(stats), F, P, C, G, _stream()), "ld_groupnorm_stats")
+
+
+def groupnorm_apply(x, out_padded, stats, gamma, beta, F, T, H, W, C, G, *, zy=None, zb=None, zshape=(1, 1, 1),
+                    tpad=0, hpad=0, wpad=0, swish=True, eps=1e-6):
+    check(_lib.load().ld_groupnorm_apply(_ptr(x), _ptr(out_padded), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(zy), _ptr(zb),
+                                         F, T, H, W, C, G, zshape[0], zshape[1], zshape[2], tpad, hpad, wpad, int(swish),
+                                         float(eps), _stream()), "ld_groupnorm_apply")
+
+
+# ------------------------------------------------------------------------------------------------
+# layout / elementwise
+# ------------------------------------------------------------------------------------------------
+def patchify(x, sem, out, p):
+    B, T, C, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    check(_lib.load().ld_patchify(_ptr(x), _ptr(sem), _ptr(out), B, T, C, H, W, p, _stream()), "ld_patchify")
+
+
+def unpatchify_cfg(lin, x, out, p, c_out, c_skip, scale):
+    _, T, C, H, W = x.shape
+    check(_lib.load().ld_unpatchify_cfg(_ptr(lin), _ptr(x), _ptr(out), T, C, H, W, p, float(c_out), float(c_skip),
+                                        float(scale), _stream()), "ld_unpatchify_cfg")
+
+
+def axpbypcz(out, x, a, y=None, b=0.0, z=None, c=0.0):
+    check(_lib.load().ld_axpbypcz(_ptr(out), _ptr(x), float(a), _ptr(y), float(b), _ptr(z), float(c), out.numel(),
+                                  _stream()), "ld_axpbypcz")
+    return out
+
+
+def timestep_embedding(t, out, max_period=10000.0):
+    B, dim = out.shape
+    check(_lib.load().ld_timestep_embedding(_ptr(t), _ptr(out), B, dim, float(max_period), _stream()),
+          "ld_timestep_embedding")
+
+
+def place_cl(x, out_padded, F, Ti, Hi, Wi, Cin, Cout, *, mode=0, time_up=False, tpad=0, hpad=1, wpad=1):
+    check(_lib.load().ld_place_cl(_ptr(x), _ptr(out_padded), F, Ti, Hi, Wi, Cin, Cout, mode, int(time_up), tpad, hpad,
+                                  wpad, _stream()), "ld_place_cl")
+
+
+def to_uint8(x, out, video, P):
+    check(_lib.load().ld_to_uint8(_ptr(x), x.stride(-2), _ptr(out), _ptr(video), P, _stream()), "ld_to_uint8")
+
+
+def latent_to_cl(x, out, T, C, H, W, Cpad, mul, src_tchw):
+    check(_lib.load().ld_latent_to_cl(_ptr(x), _ptr(out), T, C, H, W, Cpad, float(mul), int(src_tchw), _stream()),
+          "ld_latent_to_cl")

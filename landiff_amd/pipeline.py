@@ -1,0 +1,122 @@
+"""Per-prompt pipeline on one MI355X and prompt-batch data parallelism over the GPUs of a node.
+
+Stage order of landiff/infer_video.py:105-114: AR token decode (ArModelInferWrapper, landiff/llm/llm_infer.py:74-105)
+-> CogWrapper.forward (landiff/diffusion/dif_infer.py:152-243): semantic condition once per video, 50 sampler steps over
+the control+main DiT, chunked VAE decode, post-process.  Unlike the reference nothing leaves the device between the
+stages (no .npy round trip of the tokens, no model .cpu()/.cuda() shuffling, VAE caches in HBM).
+"""
+from __future__ import annotations
+
+import os
+import time
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from .config import PipelineConfig
+from .detokenizer import Detokenizer
+from .dit import ControlDiTRunner
+from .llm import LLMRunner
+from .sampler import DiffusionSampler
+from .vae import VAEDecoder
+
+
+@dataclass
+class PromptInputs:
+    """What the boundary hands to the hot path for one prompt (T5 encoders are outside the path)."""
+    llm_text_emb: torch.Tensor        # [n, text_dim]   FLAN-T5-XXL states of the prompt (LLM condition)
+    dit_context: torch.Tensor         # [1, text_len, text_dim]  T5-v1.1-XXL states, padded to text_len
+    seed: int = 42
+    cfg: float = 7.5
+    motion_score: float = 0.1
+
+
+class LanDiffPipeline:
+    def __init__(self, cfg: PipelineConfig, states: dict, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.LandiffHipError("LanDiffPipeline needs an MI355X GPU: there is no CPU fallback")
+        _lib.load()
+        self.cfg = cfg.check()
+        self.dev = torch.device(device)
+        torch.cuda.set_device(self.dev)
+        self.llm = LLMRunner(states["llm"], cfg.llm, self.dev, max_frames=cfg.llm.segment_length) if "llm" in states else None
+        self.detok = Detokenizer(states["tok"], states["ups"], cfg.tok, cfg.ups, self.dev)
+        self.dit = ControlDiTRunner(states["dit_main"], states["dit_control"], cfg.dit, self.dev)
+        self.sampler = DiffusionSampler(cfg.sampler)
+        self.vae = VAEDecoder(states["vae"], cfg.vae, self.dev)
+        self.timings = {}
+
+    def _t(self, name, t0):
+        torch.cuda.synchronize(self.dev)
+        self.timings[name] = self.timings.get(name, 0.0) + time.perf_counter() - t0
+
+    @torch.no_grad()
+    def generate_tokens(self, inp: PromptInputs) -> torch.Tensor:
+        """ArModelInferWrapper.forward: set_seed_for_single_process(seed) then Semantic1DLM.sample(seed=seed)."""
+        torch.manual_seed(inp.seed)
+        torch.cuda.manual_seed(inp.seed)
+        return self.llm.sample(inp.llm_text_emb, motion_score=inp.motion_score, num_frames=self.cfg.llm.segment_length,
+                               guidance_scale=inp.cfg, temperature=1.0, seed=inp.seed)
+
+    @torch.no_grad()
+    def generate_latent(self, tokens: torch.Tensor, inp: PromptInputs, noise: torch.Tensor | None = None) -> torch.Tensor:
+        """CogWrapper.forward up to model.sample: seeds, semantic condition, sampler.  Returns [1,T,C,h,w] fp32."""
+        d = self.cfg.dit
+        torch.manual_seed(inp.seed)
+        torch.cuda.manual_seed(inp.seed)
+        t0 = time.perf_counter()
+        sem = self.detok.semantic_condition(tokens.to(self.dev))
+        self.dit.set_condition(inp.dit_context, sem)
+        self._t("detokenize", t0)
+        t0 = time.perf_counter()
+        if noise is None:
+            noise = torch.randn(1, d.latent_frames, d.in_channels, d.latent_h, d.latent_w, device=self.dev, dtype=torch.float32)
+        z = self.sampler.run(self.dit.step, noise)
+        self._t("dit", t0)
+        return z
+
+    @torch.no_grad()
+    def decode(self, latent: torch.Tensor, want_float: bool = False):
+        t0 = time.perf_counter()
+        lat = latent.to(torch.bfloat16).float()        # samples.to(self.dtype) (diffusion_video.py:314)
+        out = self.vae.decode(lat, want_float=want_float)
+        self._t("vae", t0)
+        return out
+
+    @torch.no_grad()
+    def __call__(self, inp: PromptInputs, want_float: bool = False):
+        """prompt embeddings -> uint8 frames [4T-3, H, W, 3] in device memory (BASELINE metric region)."""
+        t0 = time.perf_counter()
+        tokens = self.generate_tokens(inp)
+        self._t("llm", t0)
+        z = self.generate_latent(tokens, inp)
+        return self.decode(z, want_float=want_float)
+
+
+def synthetic_inputs(cfg: PipelineConfig, device, n_text: int = 64, seed: int = 42) -> PromptInputs:
+    """Synthetic prompt embeddings: N(0,1), seeds 42 / 43."""
+    g = torch.Generator().manual_seed(seed)
+    llm_text = torch.randn(n_text, cfg.llm.text_dim, generator=g)
+    g2 = torch.Generator().manual_seed(seed + 1)
+    ctx = torch.randn(1, cfg.dit.text_len, cfg.dit.text_dim, generator=g2)
+    return PromptInputs(llm_text.to(device), ctx.to(device), seed=seed)
+
+
+# ------------------------------------------------------------------------------------------------
+# prompt-batch data parallelism (one process per GPU; the only collective is the final gather)
+# ------------------------------------------------------------------------------------------------
+def shard_prompts(n_prompts: int, rank: int, world: int) -> list[int]:
+    """Rank r processes prompts r, r+world, ...; each keeps the user's seed, so a prompt's result
+    does not depend on the number of GPUs."""
+    return list(range(rank, n_prompts, world))
+
+
+def gather_frames(frames: torch.Tensor, world: int):
+    """all_gather of uint8 frames [n_local, T, H, W, 3] over RCCL/xGMI (gloo on CPU in tests)."""
+    import torch.distributed as dist
+    if world == 1 or not dist.is_initialized():
+        return [frames]
+    out = [torch.empty_like(frames) for _ in range(world)]
+    dist.all_gather(out, frames.contiguous())
+    return out

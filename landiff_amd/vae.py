@@ -1,0 +1,148 @@
+"""CogVideoX 3D-VAE decode on MI355X: channels-last activations, implicit-GEMM causal convs, HBM-resident halo caches.
+
+Mirrors CogWrapper.decode_latent (landiff/diffusion/dif_infer.py:245-271: latent / 1.15258426, chunks of 3,2,2,...
+latent frames, cache cleared on the last chunk) and ContextParallelDecoder3D.forward
+(landiff/diffusion/vae_modules/cp_enc_dec.py:1034-1069) with ContextParallelCausalConv3d (:416-473),
+SpatialNorm3D (:546-569), Upsample3D (:605-633), the resblock (:745-782), then _post_process_cog_video
+(dif_infer.py:37-49) and the uint8 truncation of landiff/utils.py:327-331.
+
+Differences in mechanism, not in results: the per-conv caches of the last two padded input frames stay in HBM
+(the reference bounces them through host memory); activations are [T][H][W][C] so every conv tap is a coalesced
+128-byte row; conv_y/conv_b of SpatialNorm3D are evaluated at latent resolution and gathered with the nearest rule
+(a 1x1x1 conv commutes with nearest upsampling); GroupNorm statistics stay per chunk, as in the reference.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .config import VAEConfig
+from .detokenizer import _conv_w, _dev
+from .weights import vae_levels
+
+BF = torch.bfloat16
+ZQ_PAD = 64          # z/zq channels zero-padded 16 -> 64 for the MFMA K-tile
+
+
+class VAEDecoder:
+    def __init__(self, sd: dict, cfg: VAEConfig, device):
+        self.cfg, self.dev = cfg, device
+        self.w = {}
+        for k, v in sd.items():
+            if not k.startswith("decoder."):
+                continue
+            if k.endswith("weight") and v.dim() >= 4:
+                if v.shape[-1] == 1 and v.shape[-2] == 1:            # 1x1x1 conv -> GEMM weight, K padded to 64
+                    m = v.reshape(v.shape[0], v.shape[1])
+                    if m.shape[1] < ZQ_PAD:
+                        m = torch.nn.functional.pad(m, (0, ZQ_PAD - m.shape[1]))
+                    self.w[k] = _dev(m, device)
+                else:
+                    self.w[k] = _conv_w(v, device, cin_pad=ZQ_PAD if v.shape[1] < ZQ_PAD else None)
+            else:
+                self.w[k] = _dev(v, device)
+        self.cache = {}
+
+    # ---- building blocks (x is a plain channels-last [T*H*W, C] tensor) ----------------------
+    def _causal_conv(self, xp, name, T, H, W, clear, **epi):
+        """xp: zero-bordered [T+2][H+2][W+2][C] with the current frames at time offset 2.  Fills the 2-frame
+        halo from the cache (or by replicating the first frame), saves the next cache, runs the conv."""
+        if name in self.cache:
+            xp[:2].copy_(self.cache.pop(name))
+        else:
+            xp[0].copy_(xp[2]); xp[1].copy_(xp[2])
+        if not clear:
+            self.cache[name] = xp[T:T + 2].clone()
+        return ops.conv_cl(xp, self.w[name + ".conv.weight"], T, H, W, bias=self.w[name + ".conv.bias"], **epi)
+
+    def _spatial_norm_swish(self, x, name, T, H, W, C, zq, zshape, tpad):
+        """swish(GN(x) * conv_y(zq) + conv_b(zq)) -> zero-bordered [T+tpad][H+2][W+2][C]."""
+        cfg, dev = self.cfg, self.dev
+        zy = ops.gemm(zq, self.w[name + ".conv_y.conv.weight"], bias=self.w[name + ".conv_y.conv.bias"])
+        zb = ops.gemm(zq, self.w[name + ".conv_b.conv.weight"], bias=self.w[name + ".conv_b.conv.bias"])
+        stats = torch.empty(1, cfg.gn_groups, 2, device=dev, dtype=torch.float64)
+        ops.groupnorm_stats(x, stats, 1, T * H * W, C, cfg.gn_groups)
+        out = torch.zeros(T + tpad, H + 2, W + 2, C, device=dev, dtype=BF)
+        ops.groupnorm_apply(x, out, stats, self.w[name + ".norm_layer.weight"], self.w[name + ".norm_layer.bias"],
+                            1, T, H, W, C, cfg.gn_groups, zy=zy, zb=zb, zshape=zshape, tpad=tpad, hpad=1, wpad=1,
+                            swish=True, eps=cfg.gn_eps)
+        return out
+
+    def _resblock(self, x, p, cin, cout, T, H, W, zq, zshape, clear):
+        hp = self._spatial_norm_swish(x, p + "norm1", T, H, W, cin, zq, zshape, 2)
+        h = self._causal_conv(hp, p + "conv1", T, H, W, clear)
+        del hp
+        hp = self._spatial_norm_swish(h, p + "norm2", T, H, W, cout, zq, zshape, 2)
+        del h
+        if cin != cout:
+            x = ops.gemm(x, self.w[p + "nin_shortcut.weight"], bias=self.w[p + "nin_shortcut.bias"])
+        return self._causal_conv(hp, p + "conv2", T, H, W, clear, resid=x)
+
+    def _upsample(self, x, name, T, H, W, C, time_up):
+        To = T
+        if time_up and T > 1:
+            To = 1 + 2 * (T - 1) if T % 2 == 1 else 2 * T
+        xp = torch.zeros(To, 2 * H + 2, 2 * W + 2, C, device=self.dev, dtype=BF)
+        ops.place_cl(x, xp, 1, T, H, W, C, C, mode=1, time_up=time_up)
+        out = ops.conv_cl(xp, self.w[name + ".conv.weight"], To, 2 * H, 2 * W, bias=self.w[name + ".conv.bias"])
+        return out, To, 2 * H, 2 * W
+
+    # ---- one chunk ---------------------------------------------------------------------------
+    def decode_chunk(self, z_cl: torch.Tensor, T: int, H: int, W: int, clear: bool) -> tuple:
+        """z_cl [T*H*W, 64] bf16 channels-last latent chunk (already / scale_factor, zero-padded channels).
+        Returns (rgb [T'*8H*8W, 8] bf16 with 3 valid channels, T', 8H, 8W)."""
+        cfg = self.cfg
+        zshape = (T, H, W)
+        p = "decoder."
+        xp = torch.zeros(T + 2, H + 2, W + 2, ZQ_PAD, device=self.dev, dtype=BF)
+        ops.place_cl(z_cl, xp, 1, T, H, W, ZQ_PAD, ZQ_PAD, mode=0, tpad=2)
+        h = self._causal_conv(xp, p + "conv_in", T, H, W, clear)
+        top = h.shape[1]
+        h = self._resblock(h, p + "mid.block_1.", top, top, T, H, W, z_cl, zshape, clear)
+        h = self._resblock(h, p + "mid.block_2.", top, top, T, H, W, z_cl, zshape, clear)
+        ch = top
+        for lvl, blocks, up in vae_levels(cfg):
+            for j, (cin, cout) in enumerate(blocks):
+                h = self._resblock(h, p + f"up.{lvl}.block.{j}.", cin, cout, T, H, W, z_cl, zshape, clear)
+                ch = cout
+            if up:
+                h, T, H, W = self._upsample(h, p + f"up.{lvl}.upsample", T, H, W, ch, up == "space_time")
+        hp = self._spatial_norm_swish(h, p + "norm_out", T, H, W, ch, z_cl, zshape, 2)
+        del h
+        rgb = torch.empty(T * H * W, 8, device=self.dev, dtype=BF)
+        self._causal_conv(hp, p + "conv_out", T, H, W, clear, out=rgb[:, : cfg.out_ch])
+        return rgb, T, H, W
+
+    # ---- whole latent ------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode(self, latent: torch.Tensor, want_float: bool = False):
+        """latent [1, T, C, h, w] fp32/bf16 (sampler output) -> uint8 frames [4T-3, 8h, 8w, 3] on the device
+        (+ optionally the fp32 video [3, 4T-3, 8h, 8w] in [0,1])."""
+        cfg = self.cfg
+        _, Tl, C, h, w = latent.shape
+        lat32 = latent.float().contiguous()
+        self.cache = {}
+        loop = (Tl - 1) // 2
+        n_frames = 4 * Tl - 3
+        P_total = n_frames * 8 * h * 8 * w
+        frames = torch.empty(n_frames, 8 * h, 8 * w, 3, device=self.dev, dtype=torch.uint8)
+        video = torch.empty(3, P_total, device=self.dev, dtype=torch.float32) if want_float else None
+        f0 = 0
+        for i in range(loop):
+            a, b = (0, 3) if i == 0 else (i * 2 + 1, i * 2 + 3)
+            T = b - a
+            z_cl = torch.empty(T * h * w, ZQ_PAD, device=self.dev, dtype=BF)
+            ops.latent_to_cl(lat32[0, a:b], z_cl, T, C, h, w, ZQ_PAD, 1.0 / cfg.scale_factor, src_tchw=True)
+            rgb, To, Ho, Wo = self.decode_chunk(z_cl, T, h, w, clear=(i == loop - 1))
+            P = To * Ho * Wo
+            if want_float:   # chunk-local [3][P] then scattered into [3][frames] below
+                tmp = torch.empty(3, P, device=self.dev, dtype=torch.float32)
+                ops.to_uint8(rgb, frames[f0:f0 + To], tmp, P)
+                video.view(3, n_frames, -1)[:, f0:f0 + To] = tmp.view(3, To, -1)
+            else:
+                ops.to_uint8(rgb, frames[f0:f0 + To], None, P)
+            f0 += To
+        assert f0 == n_frames
+        if want_float:
+            return frames, video.view(3, n_frames, 8 * h, 8 * w)
+        return frames
