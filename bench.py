@@ -1,0 +1,166 @@
+"""bench.py -- end-to-end frames/sec of the LanDiff hot path on MI355X (BASELINE.json metric).
+
+One "step" = one full 49-frame 480x720 video per GPU: AR semantic-token decode (1244 steps, 2.03 B params) ->
+detokenize (TiTok decoder + conv upsampler) -> 50 sampler steps over the control+main DiT (B=2 CFG pair,
+17 776 tokens) -> chunked 3D-VAE decode -> uint8 frames resident in HBM.  Inputs (prompt embeddings) and the
+seeded random-init weights are resident in HBM before the timed region.  N > 1: one process per GPU
+(torchrun), prompts sharded data-parallel, one RCCL all_gather of the finished uint8 frames per step.
+
+  python bench.py --gpus 1 --steps 1 --warmup 1
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+METRIC = "end-to-end frames/sec, 49f 480x720 @50 steps"
+
+
+def cpu_baseline(cfg, budget_s: float = 25.0):
+    """The oracle (CPU restatement, "port") timed on the host cores on a bounded sample of the same workload:
+    one DiT layer-call at the full shape (B=2, N=17776), one LLM decode step, one TiTok decoder layer and one VAE
+    3x3x3 conv at a reduced extent; extrapolated with the multipliers of BASELINE.md section 3."""
+    import dataclasses
+    from landiff_amd.weights import dit_spec, init_state, llm_spec, tokenizer_spec
+    from oracle.dit import DiTOracle
+    from oracle.llm import LLMOracle
+    from oracle.tokenizer import DetokenizerOracle, rope3d_table, frame_ids
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    out = {}
+    with torch.no_grad():
+        d1 = dataclasses.replace(cfg.dit, layers_main=1, layers_control=1)
+        orc = DiTOracle(init_state(dit_spec(d1, False), 1), d1, False, torch.float32)
+        h = torch.randn(2, d1.seq_len, d1.hidden)
+        emb = torch.randn(2, d1.time_embed_dim)
+        t0 = time.perf_counter(); orc.layer(0, h, emb); out["dit_layer_s"] = time.perf_counter() - t0
+        l1 = dataclasses.replace(cfg.llm, num_layers=2)
+        lo = LLMOracle(init_state(llm_spec(l1), 2), l1, torch.float32)
+        cache = [(torch.randn(2, 1200, l1.heads, l1.head_dim), torch.randn(2, 1200, l1.heads, l1.head_dim)) for _ in range(2)]
+        cos, sin = torch.ones(1, 1, l1.head_dim // 2), torch.zeros(1, 1, l1.head_dim // 2)
+        x = torch.randn(2, 1, l1.hidden)
+        t0 = time.perf_counter()
+        for i in range(2):
+            x = lo.block(i, x, cache, cos, sin)
+        out["llm_layer_s"] = (time.perf_counter() - t0) / 2
+        t1 = dataclasses.replace(cfg.tok, layers=1)
+        to = DetokenizerOracle(init_state(tokenizer_spec(t1), 3), {}, t1, cfg.ups, torch.float32)
+        xt = torch.randn(1, t1.seq_len, t1.width)
+        c3, s3 = rope3d_table(t1)
+        fid = torch.from_numpy(frame_ids(t1))
+        mask = (fid[None, :] <= fid[:, None])[None, None]
+        t0 = time.perf_counter(); to.titok_block(0, xt, c3[None], s3[None], mask); out["titok_layer_s"] = time.perf_counter() - t0
+        xc = torch.randn(1, 128, 4, 120, 180)
+        wc = torch.randn(128, 128, 3, 3, 3)
+        t0 = time.perf_counter(); torch.nn.functional.conv3d(xc, wc, padding=(0, 1, 1)); dt = time.perf_counter() - t0
+        out["conv_tflops"] = 2 * 128 * 128 * 27 * 2 * 120 * 180 / dt / 1e12
+    d, l = cfg.dit, cfg.llm
+    total = (out["dit_layer_s"] * (d.layers_main + d.layers_control) * cfg.sampler.num_steps
+             + out["llm_layer_s"] * l.num_layers * 1244 + out["titok_layer_s"] * cfg.tok.layers + 315.0 / out["conv_tflops"])
+    frames = 4 * d.latent_frames - 3
+    return {"value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": ("oracle fp32 on host cores: 1 DiT layer-call (B=2,N=17776) %.1fs, 1 LLM decode layer %.3fs, 1 TiTok layer %.1fs, "
+                       "conv3d %.2f TFLOP/s; extrapolated x(45x50), x(24x1244), x12, 315 TFLOP -> %.0f s/video"
+                       % (out["dit_layer_s"], out["llm_layer_s"], out["titok_layer_s"], out["conv_tflops"], total))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tiny", action="store_true", help="tiny random-init config (plumbing check, not the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    import torch.distributed as dist
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+
+    from landiff_amd.config import PipelineConfig
+    from landiff_amd.pipeline import LanDiffPipeline, gather_frames, synthetic_inputs
+    from landiff_amd.weights import init_pipeline_state
+
+    cfg = (PipelineConfig.tiny(3) if args.tiny else PipelineConfig.full()).check()
+    states = init_pipeline_state(cfg, seed=1234, dtype=torch.bfloat16, device=dev)
+    # fp32 where the reference keeps fp32 parameters on the LLM path (norm gains, final LN, head, embedding table)
+    pipe = LanDiffPipeline(cfg, states, dev)
+    del states
+    torch.cuda.empty_cache()
+    # rank r works on prompt r (weak scaling: one prompt per GPU per step); same seed convention as a single-GPU run
+    inp = synthetic_inputs(cfg, dev, n_text=64 if not args.tiny else 6, seed=42 + rank)
+
+    def one_step():
+        frames = pipe(inp)
+        gathered = gather_frames(frames[None], world)
+        return gathered
+
+    for _ in range(args.warmup):
+        one_step()
+    pipe.timings = {}
+    pipe.dit.attn_events = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    n_frames = out[0].shape[1]
+    if rank == 0:
+        d = cfg.dit
+        ev = pipe.dit.attn_events
+        attn_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        flops = 4.0 * 2 * d.heads * d.seq_len * d.seq_len * d.head_dim      # algorithmic FLOPs of one launch
+        achieved = flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
+        peak = 2500.0
+        res = {
+            "metric": METRIC, "value": world * n_frames * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("tiny random-init plumbing config" if args.tiny else
+                                    "LanDiff 5B full pipeline, single prompt per GPU, 49f 480x720, 50 sampler steps "
+                                    "(VPSDE DPM-Solver++(2M), DynamicCFG), bf16, random-init weights at true shapes"),
+                       "frames": n_frames, "height": 8 * d.latent_h, "width": 8 * d.latent_w,
+                       "sampler_steps": cfg.sampler.num_steps, "llm_steps": 1244 if not args.tiny else None,
+                       "parallelism": f"dp{world} over prompts, RCCL all_gather of uint8 frames only"},
+            "stage_seconds_rank0": {k: round(v / args.steps, 3) for k, v in pipe.timings.items()},
+            "roofline": {"kernel": "ld_attn_kernel (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (d.heads, d.seq_len),
+                         "bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None, "launches": len(ev),
+                         "avg_launch_ms": round(attn_ms, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(PipelineConfig.full())
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,7 @@ class ControlDiTRunner:
         self.txt_main = e(B, c.text_len, d)
         self.txt_ctrl = e(B, c.text_len, d)
         self.sem = None                         # [T, C, H, W] bf16, set per video
+        self.attn_events = None                 # bench.py: list of (start, end) HIP events around every attention launch
 
     # ---- per-video setup -------------------------------------------------------------------
     def set_condition(self, context: torch.Tensor, semantic_feature: torch.Tensor):
@@ -135,7 +136,14 @@ class ControlDiTRunner:
                       shift_txt=6 * d, scale_txt=7 * d, **mod)
         ops.gemm(self.ln, lw["qkv_w"], out=self.qkv, bias=lw["qkv_b"])
         ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
-        ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5)
+        if self.attn_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5)
+            e1.record()
+            self.attn_events.append((e0, e1))
+        else:
+            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5)
         gate = dict(gate=self.ada, gate_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
         ops.gemm(self.attn.view(-1, d), lw["dense_w"], out=h_out, bias=lw["dense_b"], resid=h_in,
                  gate_off_img=2 * d, gate_off_txt=8 * d, **gate)

@@ -202,32 +202,34 @@ def vae_spec(c: VAEConfig) -> Spec:
 # ----------------------------------------------------------------------------------------------
 # seeded random init (synthetic weights for bench / parity tests)
 # ----------------------------------------------------------------------------------------------
-def init_state(spec: Spec, seed: int, dtype=torch.float32) -> dict:
+def init_state(spec: Spec, seed: int, dtype=torch.float32, device="cpu") -> dict:
     """Deterministic synthetic weights: matrices ~ N(0, 1/fan_in) (variance preserving so that
-    activations stay O(1) through deep stacks), gains ~ 1 + 0.1 N, biases ~ 0.05 N."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
+    activations stay O(1) through deep stacks), gains ~ 1 + 0.1 N, biases ~ 0.05 N.
+    device="cuda" draws on the GPU (full-size bench weights; a different stream than the CPU one)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rn = lambda shape: torch.randn(shape, generator=g, device=device)
     out = {}
     for name, shape, kind in spec:
         if kind in ("w", "w1"):
             fan_in = 1
             for d in shape[1:]:
                 fan_in *= d
-            t = torch.randn(shape, generator=g) * (fan_in ** -0.5)
+            t = rn(shape) * (fan_in ** -0.5)
         elif kind == "g":
-            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+            t = 1.0 + 0.1 * rn(shape)
         elif kind == "b":
-            t = 0.05 * torch.randn(shape, generator=g)
+            t = 0.05 * rn(shape)
         elif kind == "pos":
-            t = 0.1 * torch.randn(shape, generator=g)
+            t = 0.1 * rn(shape)
         elif kind in ("e", "e1"):
-            t = torch.randn(shape, generator=g) * (1.0 if kind == "e1" else 0.5)
+            t = rn(shape) * (1.0 if kind == "e1" else 0.5)
         else:
             raise ValueError(kind)
         out[name] = t.to(dtype)
     return out
 
 
-def init_pipeline_state(cfg: PipelineConfig, seed: int = 1234, dtype=torch.float32, parts=None) -> dict:
+def init_pipeline_state(cfg: PipelineConfig, seed: int = 1234, dtype=torch.float32, parts=None, device="cpu") -> dict:
     """{'llm','tok','ups','dit_main','dit_control','vae'} -> state dicts of synthetic weights."""
     specs = {
         "llm": lambda: llm_spec(cfg.llm), "tok": lambda: tokenizer_spec(cfg.tok),
@@ -237,7 +239,7 @@ def init_pipeline_state(cfg: PipelineConfig, seed: int = 1234, dtype=torch.float
     out = {}
     for i, (k, fn) in enumerate(specs.items()):
         if parts is None or k in parts:
-            out[k] = init_state(fn(), seed + 101 * i, dtype)
+            out[k] = init_state(fn(), seed + 101 * i, dtype, device)
     return out
 
 
