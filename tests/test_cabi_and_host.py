@@ -1,0 +1,131 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol (no compute calls without a GPU),
+and the product's host logic (schedule, forced-token schedule, mask tables, key maps) matches the goldens."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    from landiff_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "landiff_hip.h")).read()
+    declared = set(re.findall(r"\b(ld_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 24
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/landiff_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.ld_version() == 1
+    assert ctypes.sizeof(_lib.Epilogue) == 120          # layout of ld_epilogue_t
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any launch (negative code + message), so this is safe on CPU."""
+    from landiff_amd import _lib
+    lib = _lib.load()
+    rc = lib.ld_gemm_bf16(None, 0, None, None, 0, 1, 1, 64, None, None)
+    assert rc < 0 and b"null" in lib.ld_last_error()
+    rc = lib.ld_attn_fwd_bf16(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
+                              1, 1, 100, 100, 100, 0, 64, 0.125, None, None, None, None, None)
+    assert rc < 0 and b"Npad" in lib.ld_last_error()
+
+
+def test_ops_refuse_cpu_tensors():
+    from landiff_amd import _lib, ops
+    a = torch.zeros(128, 64, dtype=torch.bfloat16)
+    with pytest.raises(_lib.LandiffHipError):
+        ops.gemm(a, a)
+
+
+def test_pipeline_fails_loudly_without_gpu():
+    from landiff_amd import _lib
+    from landiff_amd.config import PipelineConfig
+    from landiff_amd.pipeline import LanDiffPipeline
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.LandiffHipError):
+        LanDiffPipeline(PipelineConfig.tiny(), {}, "cuda:0")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "landiff_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
+
+
+def test_schedule_plan_matches_reference_tables():
+    from landiff_amd.config import SamplerConfig
+    from landiff_amd.schedule import build_plan
+    g = np.load(os.path.join(G, "schedule.npz"))
+    plan = build_plan(SamplerConfig())
+    assert len(plan) == 50
+    ts = g["timesteps"].tolist()
+    assert [p.timestep for p in plan] == ts[::-1][:50]
+    assert np.array_equal(np.array([p.cfg_scale for p in plan]), g["cfg_scales"])
+    assert np.array_equal(np.array([p.c_skip for p in plan], dtype=np.float32), g["quantized"])
+    assert plan[-1].last and not plan[0].has_prev and plan[1].has_prev
+    # multipliers against an independent evaluation from the golden alpha table
+    a = torch.from_numpy(g["alpha_cumprod_sqrt"])
+    i = 7
+    cur, nxt = a[i], a[i + 1]
+    lam = lambda v: ((v ** 2 / (1 - v ** 2)) ** 0.5).log()
+    h = lam(nxt) - lam(cur)
+    assert plan[i].m1 == float(((1 - nxt ** 2) / (1 - cur ** 2)) ** 0.5 * (-h).exp())
+    assert plan[i].m2 == float((-2 * h).expm1() * nxt)
+
+
+def test_forced_token_schedule_full_size():
+    from landiff_amd.config import LLMConfig
+    from landiff_amd.llm import forced_token_schedule
+    cfg = LLMConfig()
+    S = 67
+    full_len, forced, restricted, n_visual = forced_token_schedule(cfg, S, 13)
+    assert full_len - (S + 1) == 1244 and n_visual == 1218 and len(forced) == 26
+    assert forced[S + 331] == cfg.END_I and forced[S + 332] == cfg.START_P and forced[full_len - 1] == cfg.EOS
+    assert (cfg.EOS, cfg.BOS, cfg.START_I, cfg.END_I, cfg.START_P, cfg.END_P, cfg.PAD) == tuple(range(2048, 2055))
+
+
+def test_decoder_mask_tables():
+    from landiff_amd.config import TokenizerConfig
+    from landiff_amd.detokenizer import decoder_frame_ids, rope3d_tables
+    g = np.load(os.path.join(G, "decoder_mask.npz"))
+    Tn, tpf, nI, nP = g["tiny_cfg"].tolist()
+    cfg = TokenizerConfig(grid_h=1, grid_w=tpf, temporal=Tn, pframe_tokens=nP, num_latent_tokens=nI + (Tn - 1) * nP)
+    fid = decoder_frame_ids(cfg)
+    assert np.array_equal(fid[None, :] <= fid[:, None], g["tiny_dense"])
+    r = np.load(os.path.join(G, "rope.npz"))
+    Tn, H, W, nI, nP = r["grid"].tolist()
+    cfg = TokenizerConfig(width=128, heads=2, grid_h=H, grid_w=W, temporal=Tn, pframe_tokens=nP, num_latent_tokens=nI + (Tn - 1) * nP)
+    c3, s3 = rope3d_tables(cfg)
+    assert np.array_equal(c3.numpy(), r["f3_real"]) and np.array_equal(s3.numpy(), r["f3_imag"])
+
+
+def test_full_size_key_map_shapes():
+    from landiff_amd.config import PipelineConfig
+    from landiff_amd.weights import dit_spec, llm_spec, tokenizer_spec, upsampler_spec, vae_spec
+    cfg = PipelineConfig.full().check()
+    n = lambda spec: sum(int(np.prod(s)) for _, s, _ in spec)
+    assert abs(n([x for x in llm_spec(cfg.llm) if x[0].startswith("transformer.")]) / 1e6 - 2030.2) < 1.0   # Appendix A
+    dec = [x for x in tokenizer_spec(cfg.tok) if x[0].startswith("decoder.")]
+    assert abs(n(dec) / 1e6 - 88.0) < 0.5
+    assert abs(n([x for x in upsampler_spec(cfg.ups) if x[0].startswith("upsample_model.")]) / 1e6 - 39.2) < 0.3
+    assert abs(n(vae_spec(cfg.vae)) / 1e6 - 123.4) < 0.5
+    shapes = {k: s for k, s, _ in dit_spec(cfg.dit, True)}
+    assert shapes["mixins.pos_embed.pos_embedding"] == (1, 17776, 1920)
+    assert shapes["mixins.adaln_layer.adaLN_modulations.0.1.weight"] == (23040, 512)
+    assert shapes["mixins.adaln_layer.zero_linears.14.weight"] == (1920, 1920)
+
+
+def test_prompt_sharding():
+    from landiff_amd.pipeline import shard_prompts
+    assert shard_prompts(8, 3, 8) == [3] and shard_prompts(10, 1, 4) == [1, 5, 9]
+    allp = sorted(sum((shard_prompts(13, r, 4) for r in range(4)), []))
+    assert allp == list(range(13))

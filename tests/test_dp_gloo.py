@@ -1,0 +1,42 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard prompts and gather uint8 frames (RCCL on the GPU node)."""
+import os
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from landiff_amd.pipeline import gather_frames, shard_prompts
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_prompts(4, rank, world)
+    # stand-in frames: a deterministic function of the prompt id (the pipeline itself needs a GPU)
+    frames = torch.stack([torch.full((3, 4, 6, 3), 10 * p + 1, dtype=torch.uint8) for p in mine])
+    gathered = gather_frames(frames, world)
+    ok = len(gathered) == world
+    for r, g in enumerate(gathered):
+        ids = shard_prompts(4, r, world)
+        ok &= all(bool((g[i] == 10 * p + 1).all()) for i, p in enumerate(ids))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok, mine))
+
+
+def test_two_rank_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res)
+    assert sorted(sum((m for _, _, m in res), [])) == [0, 1, 2, 3]
