@@ -113,9 +113,10 @@ int ld_llm_rope_append(const void* qkv, const float* cos_t, const float* sin_t, 
                        int64_t Lmax, void* stream);
 
 /* Attention of query j (position *pos + j) over keys [0, *pos + j] (transformer_blocks.py:166-186):
- * bf16 scores, bf16(score / sqrt(128)), fp32 softmax -> bf16 p, bf16 output [B][m][H][128]. */
+ * bf16 scores, bf16(score / sqrt(128)), fp32 softmax -> bf16 p, bf16 output [B][m][H][128].
+ * m == 1 with nsplit > 1 uses the key-split path (workspace: B*H*nsplit*130 floats, caller-owned; p kept fp32). */
 int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
-                   int64_t B, int64_t m, int64_t H, int64_t Lmax, void* stream);
+                   int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit, void* stream);
 
 /* nn.Embedding lookup of *token (fp32 table [V][D]) -> bf16 features [B][D] (landiff/llm/modules/tokenizer.py:10-55). */
 int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B, int64_t D, void* stream);

@@ -26,6 +26,8 @@
 //     tiles (no load, no MFMA) and apply the element mask only on the few straddling tiles.
 #include "ld_common.h"
 #include "../../include/landiff_hip.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -66,18 +68,28 @@ __device__ __forceinline__ float lane32_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// v_max3_f32 by hand: plain fmaxf on MFMA outputs makes hipcc insert a canonicalising v_max per operand
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 __device__ __forceinline__ int swap23(int i) {
   return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
 
+template <int TPS, bool DEFER, bool PRIO>   // 64-key tiles per LDS stage (per barrier)
 __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + 64];
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x TPS x (K 8 KB + V^T 8 KB) + 64 B
+  constexpr int STAGE = TPS * STAGE_BYTES;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5;
   const int nqb = p.Npad / QB;
   const int nkt_all = (p.Nk + KT - 1) / KT;
+  const int nst_all = (nkt_all + TPS - 1) / TPS;
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = bid / nqb, qb = bid - bh * nqb;
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
       mx = max(mx, __shfl_xor(mx, o, 64));
     }
     wqmin = mn; wqmax = mx;
-    int* red = (int*)(smem + 2 * STAGE_BYTES);
+    int* red = (int*)(smem + 2 * STAGE);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     bqmax = max(max(red[0], red[1]), max(red[2], red[3]));
@@ -122,56 +134,68 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
   int ldsoff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int idx = wave * 4 + i;            // 0..15 (1 KB pieces)
+    const int idx = wave * 4 + i;            // 0..15 (1 KB pieces of one 64-key tile)
     const int r = (idx & 7) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((r >> 1) & 7);
     if (idx < 8) goff[i] = (long)r * D + chunk * 8;          // + kv0 * D
     else goff[i] = (long)r * p.Npad + chunk * 8;             // + kv0
     ldsoff[i] = (idx < 8 ? 0 : KTILE_BYTES) + (idx & 7) * 1024;
   }
-  auto stage = [&](int buf, int t) {
-    const long kv0 = (long)t * KT;
-    char* base = smem + buf * STAGE_BYTES;
+  auto stage = [&](int buf, int st) {
+    char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = wave * 4 + i;
-      const bf16_t* src = (idx < 8) ? (Kb + kv0 * D + goff[i]) : (Vb + kv0 + goff[i]);
-      glds16(src, base + ldsoff[i]);
+    for (int j = 0; j < TPS; ++j) {
+      const int t = st * TPS + j;
+      if (t < nkt_all) {
+        const long kv0 = (long)t * KT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = wave * 4 + i;
+          const bf16_t* src = (idx < 8) ? (Kb + kv0 * D + goff[i]) : (Vb + kv0 + goff[i]);
+          glds16(src, base + j * STAGE_BYTES + ldsoff[i]);
+        }
+      }
     }
   };
-  auto next_tile = [&](int t) {
-    ++t;
-    if (masked) { while (t < nkt_all && p.kt_min[t] > bqmax) ++t; }
-    return t;
+  auto stage_needed = [&](int st) {
+    if (!masked) return true;
+    bool need = false;
+#pragma unroll
+    for (int j = 0; j < TPS; ++j) {
+      const int t = st * TPS + j;
+      if (t < nkt_all && p.kt_min[t] <= bqmax) need = true;
+    }
+    return need;
+  };
+  auto next_stage = [&](int st) {
+    ++st;
+    while (st < nst_all && !stage_needed(st)) ++st;
+    return st;
   };
 
-  // fragment read addresses
-  int kaddr[2], kkey[2], vaddr[2], vkey[2];
+  // fragment read byte offsets within a 64-key tile, one per (row block i, k-step): loop invariant, so the
+  // per-tile LDS addressing is just "register + immediate" (the stage/buffer offsets are compile-time constants)
+  int kofs[2][4], vofs[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int key = i * 32 + swap23(lane & 31);
-    kaddr[i] = key * 128; kkey[i] = (key >> 1) & 7;
     const int d = i * 32 + (lane & 31);
-    vaddr[i] = KTILE_BYTES + d * 128; vkey[i] = (d >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = kk * 2 + hi;
+      kofs[i][kk] = key * 128 + ((c ^ ((key >> 1) & 7)) << 4);
+      vofs[i][kk] = KTILE_BYTES + d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
+    }
   }
 
   f32x16_t o[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m = NEG_BIG, lsum = 0.f;
+  const float thr = 8.0f / p.c;     // defer the O rescale while the running max grows by < 2^8 (exp2 domain)
 
-  int t = -1;
-  t = next_tile(t);
-  if (t < nkt_all) stage(0, t);
-  int buf = 0;
-  while (t < nkt_all) {
-    const int tn = next_tile(t);
-    __syncthreads();
-    if (tn < nkt_all) stage(buf ^ 1, tn);
-    const char* sb = smem + buf * STAGE_BYTES;
-
+  auto tile = [&](auto bufc, auto jc, int t) {
+    constexpr int OFF = decltype(bufc)::value * STAGE + decltype(jc)::value * STAGE_BYTES;
     bool skip = false, need_mask = false;
     if (masked) {
       const int tmin = p.kt_min[t], tmax = p.kt_max[t];
@@ -180,86 +204,112 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
     } else {
       need_mask = (t + 1) * KT > p.Nk;
     }
-    if (!skip) {
-      // ---- S^T = K Q^T ----
-      f32x16_t st[2];
+    if (skip) return;
+    // ---- S^T = K Q^T: all 8 K fragments are requested up front (one exposed LDS latency per tile, not four);
+    //      the first k-step uses the inline-constant 0 as C, so the accumulators are never zeroed by VALU moves ----
+    f32x16_t sacc[2];
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bf16x8_t kf[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) kf[i][kk] = *(const bf16x8_t*)(smem + kofs[i][kk] + OFF);
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][kk], qf[kk], kk == 0 ? zero16 : sacc[i], 0, 0, 0);
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    // V^T fragments for the PV product: requested now so their LDS latency hides under the softmax VALU work
+    bf16x8_t vf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) vf[i][ks] = *(const bf16x8_t*)(smem + vofs[i][ks] + OFF);
+    // register r of sacc[i] holds key  t*64 + i*32 + (r>>3)*16 + hi*8 + (r&7)
+    if (need_mask) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[i][r] = 0.f;
+        for (int g = 0; g < 2; ++g) {
+          const int key0 = t * KT + i * 32 + g * 16 + hi * 8;
+          if (masked) {
+            const int4 f0 = *(const int4*)(p.fid_k + key0);
+            const int4 f1 = *(const int4*)(p.fid_k + key0 + 4);
+            const int f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int c = kk * 2 + hi;
+            for (int e = 0; e < 8; ++e)
+              if (f[e] > qfid) sacc[i][g * 8 + e] = NEG_BIG;
+          } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const bf16x8_t a = *(const bf16x8_t*)(sb + kaddr[i] + ((c ^ kkey[i]) << 4));
-          st[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], st[i], 0, 0, 0);
-        }
-      }
-      // register r of st[i] holds key  t*64 + i*32 + (r>>3)*16 + hi*8 + (r&7)
-      if (need_mask) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            const int key0 = t * KT + i * 32 + g * 16 + hi * 8;
-            if (masked) {
-              const int4 f0 = *(const int4*)(p.fid_k + key0);
-              const int4 f1 = *(const int4*)(p.fid_k + key0 + 4);
-              const int f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-#pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (f[e] > qfid) st[i][g * 8 + e] = NEG_BIG;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (key0 + e >= p.Nk) st[i][g * 8 + e] = NEG_BIG;
-            }
+            for (int e = 0; e < 8; ++e)
+              if (key0 + e >= p.Nk) sacc[i][g * 8 + e] = NEG_BIG;
           }
-      }
-      // ---- online softmax (per query column; lane and lane^32 share the row) ----
-      float mx = st[0][0];
+        }
+    }
+    // ---- online softmax (per query column; lane and lane^32 share the row) ----
+    float mx = max3f(sacc[0][0], sacc[1][0], sacc[0][1]);
+    mx = max3f(mx, sacc[1][1], sacc[0][2]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[i][r]);
-      mx = lane32_max(mx);
+    for (int r = 2; r < 15; ++r) mx = max3f(mx, sacc[1][r], sacc[0][r + 1]);
+    mx = fmaxf(mx, sacc[1][15]);
+    mx = lane32_max(mx);
+    if (!DEFER || !__all(mx - m <= thr)) {   // rare after the first tiles: rescale everything held at the old max
       const float mnew = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f((m - mnew) * p.c);
-      const float mc = mnew * p.c;
       m = mnew;
-      float psum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(st[i][r], p.c, -mc));
-          st[i][r] = pv;
-          psum += pv;
-        }
-      lsum = lsum * alpha + psum;
+      lsum *= alpha;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-      // ---- O^T += V^T P^T ----
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4_t pw;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          pw[e] = pack_bf16x2(st[ks >> 1][(ks & 1) * 8 + 2 * e], st[ks >> 1][(ks & 1) * 8 + 2 * e + 1]);
-        const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
-        const int c = ks * 2 + hi;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const bf16x8_t a = *(const bf16x8_t*)(sb + vaddr[i] + ((c ^ vkey[i]) << 4));
-          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[i], 0, 0, 0);
-        }
-      }
     }
-    t = tn;
-    buf ^= 1;
+    const float mc = m * p.c;
+    float psum = 0.f;                  // (packed v_pk_fma/v_pk_add were measured slower beside the MFMAs: -3 %)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[i][r], p.c, -mc));
+        sacc[i][r] = pv;
+        psum += pv;
+      }
+    lsum += psum;
+    // ---- O^T += V^T P^T ----
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4_t pw;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        pw[e] = pack_bf16x2(sacc[ks >> 1][(ks & 1) * 8 + 2 * e], sacc[ks >> 1][(ks & 1) * 8 + 2 * e + 1]);
+      const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][ks], pb, o[i], 0, 0, 0);
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  auto stage_tiles = [&](auto bufc, int st) {
+    tile(bufc, std::integral_constant<int, 0>{}, st * TPS);
+    if (TPS > 1 && st * TPS + 1 < nkt_all) tile(bufc, std::integral_constant<int, TPS - 1>{}, st * TPS + 1);
+  };
+
+  int st = next_stage(-1);
+  if (st < nst_all) stage(0, st);
+  while (st < nst_all) {
+    int stn = next_stage(st);
+    __syncthreads();
+    if (stn < nst_all) stage(1, stn);
+    stage_tiles(std::integral_constant<int, 0>{}, st);
+    st = stn;
+    if (st >= nst_all) break;
+    stn = next_stage(st);
+    __syncthreads();
+    if (stn < nst_all) stage(0, stn);
+    stage_tiles(std::integral_constant<int, 1>{}, st);
+    st = stn;
   }
 
   // ---- finalize: O = O^T / l, write bf16 rows ----
@@ -301,6 +351,26 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   p.fid_q = fid_q; p.fid_k = fid_k; p.kt_min = kt_min; p.kt_max = kt_max;
   const int nqb = (int)(Npad / QB);
   dim3 grid((unsigned)(B * H * nqb)), block(256);
-  hipLaunchKernelGGL(ld_attn_kernel, grid, block, 0, (hipStream_t)stream, p);
+  static int var = -1;
+  if (var < 0) {
+    const char* e = getenv("LD_ATTN_VARIANT");     // bit0: TPS=2, bit1: DEFER, bit2: PRIO (tuning knob)
+    var = e ? atoi(e) : 2;                          // default: 1 tile/stage, deferred rescale, no setprio (measured best)
+    (void)hipFuncSetAttribute((const void*)ld_attn_kernel<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES + 64);
+    (void)hipFuncSetAttribute((const void*)ld_attn_kernel<2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES + 64);
+    (void)hipFuncSetAttribute((const void*)ld_attn_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES + 64);
+    (void)hipFuncSetAttribute((const void*)ld_attn_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES + 64);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t s1 = 2 * STAGE_BYTES + 64, s2 = 4 * STAGE_BYTES + 64;
+  switch (var & 7) {
+    case 0: hipLaunchKernelGGL((ld_attn_kernel<1, false, false>), grid, block, s1, st, p); break;
+    case 1: hipLaunchKernelGGL((ld_attn_kernel<2, false, false>), grid, block, s2, st, p); break;
+    case 2: hipLaunchKernelGGL((ld_attn_kernel<1, true, false>), grid, block, s1, st, p); break;
+    case 3: hipLaunchKernelGGL((ld_attn_kernel<2, true, false>), grid, block, s2, st, p); break;
+    case 4: hipLaunchKernelGGL((ld_attn_kernel<1, false, true>), grid, block, s1, st, p); break;
+    case 5: hipLaunchKernelGGL((ld_attn_kernel<2, false, true>), grid, block, s2, st, p); break;
+    case 6: hipLaunchKernelGGL((ld_attn_kernel<1, true, true>), grid, block, s1, st, p); break;
+    default: hipLaunchKernelGGL((ld_attn_kernel<2, true, true>), grid, block, s2, st, p); break;
+  }
   return ld_check_launch("ld_attn_fwd_bf16");
 }

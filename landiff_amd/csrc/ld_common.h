@@ -34,18 +34,17 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 __device__ __forceinline__ float bf2f(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
-  uint32_t r = 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)((u + r) >> 16);
+// gfx950 has a native RNE pack-convert (v_cvt_pk_bf16_f32); clang emits it for float -> __bf16 conversions.
+typedef __attribute__((ext_vector_type(2))) float ld_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 ld_bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  ld_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ld_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 // round an f32 value to the nearest bf16 and return it as f32 (emulates a bf16 op output)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
-}
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 

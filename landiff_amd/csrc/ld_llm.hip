@@ -249,6 +249,105 @@ __global__ __launch_bounds__(256) void ld_kv_attn_kernel(const bf16_t* q, const 
   if (tid < 128) out[((long)(b * m + j) * H + h) * D + tid] = f2bf(part[tid] + part[128 + tid]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decode-step (m = 1) KV attention split over the key axis ("flash decoding"): grid (B*H, nsplit) so that the
+// 2 x 16 (batch, head) pairs still fill 256 CUs.  Each workgroup writes (max, sum, unnormalised out[128]) for its
+// key range; ld_kv_attn_combine_kernel merges them.  16 lanes x 8 dims per key, 16 keys per workgroup iteration,
+// every K/V row is read once with 16-byte loads.  (p stays fp32 here; the reference rounds the normalised p to
+// bf16 before the PV product -- a <= 2^-9 relative, zero-mean difference per term.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, const bf16_t* kc, const bf16_t* vc,
+                                                               const int* pos_ptr, float* ws, int B, int H, int Lmax, int nsplit) {
+  extern __shared__ float sc[];       // [chunk] scores + reductions
+  const int D = 128;
+  const int bh = blockIdx.x, sp = blockIdx.y;
+  const int b = bh / H, h = bh - b * H;
+  const int L = *pos_ptr + 1;
+  const int chunk = (L + nsplit - 1) / nsplit;
+  const int k_begin = sp * chunk, k_end = min(L, k_begin + chunk);
+  const int n = max(0, k_end - k_begin);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 15, kq = lane >> 4;
+  float* out_ws = ws + ((long)bh * nsplit + sp) * (D + 2);
+  float* red = sc + ((Lmax + nsplit - 1) / nsplit + 16);
+  if (n == 0) {
+    if (tid < D) out_ws[2 + tid] = 0.f;
+    if (tid == 0) { out_ws[0] = -3.0e38f; out_ws[1] = 0.f; }
+    return;
+  }
+  const bf16_t* qv = q + ((long)b * H + h) * D;
+  float qreg[8];
+  {
+    const u32x4_t a = *(const u32x4_t*)(qv + sub * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { qreg[2 * e] = bf_lo(a[e]); qreg[2 * e + 1] = bf_hi(a[e]); }
+  }
+  const float inv_sqrt_d = 0.08838834764831845f;
+  float lmax = -3.0e38f;
+  for (int k0 = wave * 4; k0 < n; k0 += 16) {
+    const int kk = k0 + kq;
+    float d = 0.f;
+    if (kk < n) {
+      const u32x4_t a = *(const u32x4_t*)(kc + (((long)b * Lmax + k_begin + kk) * H + h) * D + sub * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d = fmaf(qreg[2 * e], bf_lo(a[e]), d); d = fmaf(qreg[2 * e + 1], bf_hi(a[e]), d); }
+    }
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+    if (kk < n) {
+      const float s = rbf(rbf(d) * inv_sqrt_d);
+      if (sub == 0) sc[kk] = s;
+      lmax = fmaxf(lmax, s);
+    }
+  }
+  lmax = wave_max(lmax);
+  if (lane == 0) red[wave] = lmax;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  float lsum = 0.f;
+  for (int k0 = wave * 4; k0 < n; k0 += 16) {
+    const int kk = k0 + kq;
+    if (kk < n) {
+      const float pk = __expf(sc[kk] - mx);
+      if (sub == 0) lsum += pk;
+      const u32x4_t a = *(const u32x4_t*)(vc + (((long)b * Lmax + k_begin + kk) * H + h) * D + sub * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] = fmaf(pk, bf_lo(a[e]), acc[2 * e]); acc[2 * e + 1] = fmaf(pk, bf_hi(a[e]), acc[2 * e + 1]); }
+    }
+  }
+  // reduce over the 4 key groups of a wave (lanes sub, sub+16, sub+32, sub+48), then over waves via LDS
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { acc[e] += __shfl_xor(acc[e], 16, 64); acc[e] += __shfl_xor(acc[e], 32, 64); }
+  lsum = wave_sum(lsum);
+  __syncthreads();
+  float* part = red + 8;     // [4][128]
+  if (kq == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[wave * D + sub * 8 + e] = acc[e];
+  }
+  if (lane == 0) red[4 + wave] = lsum;
+  __syncthreads();
+  if (tid < D) out_ws[2 + tid] = part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid];
+  if (tid == 0) { out_ws[0] = mx; out_ws[1] = red[4] + red[5] + red[6] + red[7]; }
+}
+
+__global__ __launch_bounds__(128) void ld_kv_attn_combine_kernel(const float* ws, bf16_t* out, int nsplit) {
+  const int D = 128;
+  const int bh = blockIdx.x, d = threadIdx.x;
+  const float* w = ws + (long)bh * nsplit * (D + 2);
+  float mx = -3.0e38f;
+  for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, w[s * (D + 2)]);
+  float l = 0.f, o = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float f = __expf(w[s * (D + 2)] - mx);
+    l += f * w[s * (D + 2) + 1];
+    o += f * w[s * (D + 2) + 2 + d];
+  }
+  out[(long)bh * D + d] = f2bf(o / l);
+}
+
 // token embedding rows (fp32 table) -> bf16 features, same token for every batch row
 __global__ void ld_embed_kernel(const float* table, const long* token, bf16_t* out, int B, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,8 +469,19 @@ LD_API int ld_llm_rope_append(const void* qkv, const float* cos_t, const float* 
 }
 
 LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
-                          int64_t B, int64_t m, int64_t H, int64_t Lmax, void* stream) {
+                          int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit, void* stream) {
   LD_REQUIRE(q && k_cache && v_cache && pos && out, "ld_llm_kv_attn: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (m == 1 && nsplit > 1) {
+    LD_REQUIRE(workspace, "ld_llm_kv_attn: split path needs a workspace of B*H*nsplit*130 floats");
+    const size_t chunk = (size_t)((Lmax + nsplit - 1) / nsplit + 16);
+    const size_t smem = (chunk + 8 + 4 * 128) * sizeof(float);
+    hipLaunchKernelGGL(ld_kv_attn_split_kernel, dim3((unsigned)(B * H), (unsigned)nsplit), dim3(256), smem, st,
+                       (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, (const int*)pos, workspace,
+                       (int)B, (int)H, (int)Lmax, (int)nsplit);
+    hipLaunchKernelGGL(ld_kv_attn_combine_kernel, dim3((unsigned)(B * H)), dim3(128), 0, st, workspace, (bf16_t*)out, (int)nsplit);
+    return ld_check_launch("ld_llm_kv_attn(split)");
+  }
   const size_t smem = (size_t)(Lmax + 8 + 256) * sizeof(float);
   LD_REQUIRE(smem <= 160 * 1024, "ld_llm_kv_attn: Lmax=%ld too long for the LDS score buffer", (long)Lmax);
   static size_t attr = 0;
@@ -379,7 +489,7 @@ LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cach
     (void)hipFuncSetAttribute((const void*)ld_kv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = smem;
   }
-  hipLaunchKernelGGL(ld_kv_attn_kernel, dim3((unsigned)(B * H), (unsigned)m), dim3(256), smem, (hipStream_t)stream,
+  hipLaunchKernelGGL(ld_kv_attn_kernel, dim3((unsigned)(B * H), (unsigned)m), dim3(256), smem, st,
                      (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, (const int*)pos,
                      (bf16_t*)out, (int)B, (int)m, (int)H, (int)Lmax);
   return ld_check_launch("ld_llm_kv_attn");

@@ -114,6 +114,8 @@ class LLMRunner:
         self.logits = e(B, c.vocab, dt=torch.float32)
         self.probs = e(1, c.vocab, dt=torch.float32)
         self.cfg_logits = e(1, c.vocab, dt=torch.float32)
+        self.nsplit = max(1, 256 // (B * H))
+        self.attn_ws = e(B * H * self.nsplit * 130, dt=torch.float32)
         self._graph = None
 
     # ---- conditioning ------------------------------------------------------------------------
@@ -182,7 +184,8 @@ class LLMRunner:
             ops.rmsnorm(self.x, w["n0"], self.xn, c.rms_eps)
             ops.gemv(self.xn, w["wqkv"], self.qkv)
             ops.llm_rope_append(self.qkv, self.cos, self.sin, self.pos, self.qr, self.kc[i], self.vc[i], B, 1, c.heads, self.Lmax)
-            ops.llm_kv_attn(self.qr, self.kc[i], self.vc[i], self.pos, self.att, B, 1, c.heads, self.Lmax)
+            ops.llm_kv_attn(self.qr, self.kc[i], self.vc[i], self.pos, self.att, B, 1, c.heads, self.Lmax,
+                            workspace=self.attn_ws, nsplit=self.nsplit)
             ops.gemv(self.att, w["wo"], self.x, resid=self.x)
             ops.rmsnorm(self.x, w["n1"], self.xn, c.rms_eps)
             ops.gemv(self.xn, w["w1"], self.gate, w2=w["w3"], act="gelu_tanh")

@@ -157,9 +157,9 @@ def llm_rope_append(qkv, cos_t, sin_t, pos, q_out, k_cache, v_cache, B, m, H, Lm
                                          _ptr(v_cache), B, m, H, Lmax, _stream()), "ld_llm_rope_append")
 
 
-def llm_kv_attn(q, k_cache, v_cache, pos, out, B, m, H, Lmax):
+def llm_kv_attn(q, k_cache, v_cache, pos, out, B, m, H, Lmax, workspace=None, nsplit=1):
     check(_lib.load().ld_llm_kv_attn(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(pos), _ptr(out), B, m, H, Lmax,
-                                     _stream()), "ld_llm_kv_attn")
+                                     _ptr(workspace), nsplit, _stream()), "ld_llm_kv_attn")
 
 
 def llm_embed(table, token, out):
