@@ -296,6 +296,8 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
     if (TPS > 1 && st * TPS + 1 < nkt_all) tile(bufc, std::integral_constant<int, TPS - 1>{}, st * TPS + 1);
   };
 
+  // two stages per trip with compile-time buffer indices; the second half sits under an `if`, not behind a `break`
+  // (a mid-loop exit makes hipcc keep two copies of the O accumulators and shuffle them every trip)
   int st = next_stage(-1);
   if (st < nst_all) stage(0, st);
   while (st < nst_all) {
@@ -304,12 +306,13 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
     if (stn < nst_all) stage(1, stn);
     stage_tiles(std::integral_constant<int, 0>{}, st);
     st = stn;
-    if (st >= nst_all) break;
-    stn = next_stage(st);
-    __syncthreads();
-    if (stn < nst_all) stage(0, stn);
-    stage_tiles(std::integral_constant<int, 1>{}, st);
-    st = stn;
+    if (st < nst_all) {
+      stn = next_stage(st);
+      __syncthreads();
+      if (stn < nst_all) stage(0, stn);
+      stage_tiles(std::integral_constant<int, 1>{}, st);
+      st = stn;
+    }
   }
 
   // ---- finalize: O = O^T / l, write bf16 rows ----

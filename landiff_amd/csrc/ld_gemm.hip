@@ -25,14 +25,13 @@
 //   * blockIdx is remapped so that consecutive tiles of one A panel sit on one XCD (private L2).
 #include "ld_common.h"
 #include "../../include/landiff_hip.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
-constexpr int CW_STRIDE = 68;                    // fp32 row stride of the epilogue staging tile
-constexpr int SMEM_BYTES = 4 * 64 * CW_STRIDE * 4;  // 69632 >= 2 * STAGE_BYTES (65536)
+constexpr int BK = 64;
+constexpr int CW_STRIDE = 68;                    // fp32 row stride of the epilogue staging tile (64 cols + pad)
 
 struct GemmParams {
   const bf16_t* A;
@@ -59,35 +58,135 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <bool CONV>
-__global__ __launch_bounds__(256, 2) void ld_gemm_kernel(GemmParams p) {
+// epilogue on 8 consecutive columns of one output row
+__device__ __forceinline__ void epilogue_store8(const GemmParams& p, float (&v)[8], int gm, int gn0, bool vec_ok) {
+  const int nvalid = (p.N - gn0) < 8 ? (p.N - gn0) : 8;
+  const bf16_t* gate_row = nullptr;
+  if (p.gate) {
+    const int b = gm / p.rows_per_batch;
+    const int rin = gm - b * p.rows_per_batch;
+    gate_row = p.gate + b * p.gate_bstride + (rin < p.text_len ? p.gate_off_txt : p.gate_off_img);
+  }
+  if (vec_ok) {
+    float bias[8], mulv[8], gt[8], rs[8], ad[8];
+    if (p.bias) {
+      const u32x4_t bw = *(const u32x4_t*)(p.bias + gn0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias[2 * e] = bf_lo(bw[e]); bias[2 * e + 1] = bf_hi(bw[e]); }
+    }
+    if (p.mul) {
+      const u32x4_t mw = *(const u32x4_t*)(p.mul + (long)gm * p.ldmul + gn0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { mulv[2 * e] = bf_lo(mw[e]); mulv[2 * e + 1] = bf_hi(mw[e]); }
+    }
+    if (gate_row) {
+      const u32x4_t gw = *(const u32x4_t*)(gate_row + gn0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gt[2 * e] = bf_lo(gw[e]); gt[2 * e + 1] = bf_hi(gw[e]); }
+    }
+    if (p.resid) {
+      if (p.resid_f32) {
+        const f32x4_t r0 = *(const f32x4_t*)((const float*)p.resid + (long)gm * p.ldr + gn0);
+        const f32x4_t r1 = *(const f32x4_t*)((const float*)p.resid + (long)gm * p.ldr + gn0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rs[e] = r0[e]; rs[4 + e] = r1[e]; }
+      } else {
+        const u32x4_t rw = *(const u32x4_t*)((const bf16_t*)p.resid + (long)gm * p.ldr + gn0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rs[2 * e] = bf_lo(rw[e]); rs[2 * e + 1] = bf_hi(rw[e]); }
+      }
+    }
+    if (p.add2) {
+      const u32x4_t aw = *(const u32x4_t*)(p.add2 + (long)gm * p.ldadd + gn0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ad[2 * e] = bf_lo(aw[e]); ad[2 * e + 1] = bf_hi(aw[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e];
+      if (p.bias) x += bias[e];
+      x = rbf(x);                                   // bf16 Linear/conv output
+      if (p.act) x = rbf(apply_act(p.act, x));
+      if (p.mul) x = rbf(x * mulv[e]);
+      if (gate_row) x = rbf(x * gt[e]);
+      if (p.resid) { x = rs[e] + x; if (!p.out_f32) x = rbf(x); }
+      if (p.add2) { x = x + ad[e]; if (!p.out_f32) x = rbf(x); }
+      v[e] = x;
+    }
+    if (p.out_f32) {
+      float* o = (float*)p.out + (long)gm * p.ldo + gn0;
+      *(f32x4_t*)o = (f32x4_t){v[0], v[1], v[2], v[3]};
+      *(f32x4_t*)(o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+    } else {
+      u32x4_t ow;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ow[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+      *(u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0) = ow;
+    }
+  } else {
+    for (int e = 0; e < nvalid; ++e) {
+      const int gn = gn0 + e;
+      float x = v[e];
+      if (p.bias) x += bf2f(p.bias[gn]);
+      x = rbf(x);
+      if (p.act) x = rbf(apply_act(p.act, x));
+      if (p.mul) x = rbf(x * bf2f(p.mul[(long)gm * p.ldmul + gn]));
+      if (gate_row) x = rbf(x * bf2f(gate_row[gn]));
+      if (p.resid) {
+        const float r = p.resid_f32 ? ((const float*)p.resid)[(long)gm * p.ldr + gn]
+                                    : bf2f(((const bf16_t*)p.resid)[(long)gm * p.ldr + gn]);
+        x = r + x; if (!p.out_f32) x = rbf(x);
+      }
+      if (p.add2) { x = x + bf2f(p.add2[(long)gm * p.ldadd + gn]); if (!p.out_f32) x = rbf(x); }
+      if (p.out_f32) ((float*)p.out)[(long)gm * p.ldo + gn] = x;
+      else ((bf16_t*)p.out)[(long)gm * p.ldo + gn] = f2bf(x);
+    }
+  }
+}
+
+// Block tile BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN) = MI x NI MFMA 32x32 tiles.
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm_kernel(GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int NT = NW * 64;
+  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_LOADS = BM / 8 / NW, B_LOADS = BN / 8 / NW;     // 1 KB LDS-DMA pieces per wave
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+  static_assert(BN / WN == 64, "epilogue staging assumes 64-column wave tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
 
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, nbm * nbn);
   const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
 
-  // ---- per-thread source row offsets (4 rows of A, 4 rows of W per K-tile) ----
-  long offA[4], offW[4];
+  // ---- per-thread source row offsets ----
+  uint32_t offA[A_LOADS], offW[B_LOADS];    // element offsets (< 2^31 for every shape on the path)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int r = (wave * A_LOADS + i) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((r >> 1) & 7);   // source-side swizzle
     int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
-    int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
     if (CONV) {
       const int hw = p.H * p.W_;
       const int t = gm / hw, rem = gm - t * hw;
       const int h = rem / p.W_, w = rem - h * p.W_;
-      offA[i] = (((long)t * p.Hp + h) * p.Wp + w) * p.Cin + chunk * 8;
+      offA[i] = (uint32_t)((((long)t * p.Hp + h) * p.Wp + w) * p.Cin + chunk * 8);
     } else {
-      offA[i] = (long)gm * p.lda + chunk * 8;
+      offA[i] = (uint32_t)((long)gm * p.lda + chunk * 8);
     }
-    offW[i] = (long)gn * p.K + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int r = (wave * B_LOADS + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+    offW[i] = (uint32_t)((long)gn * p.K + chunk * 8);
   }
 
   const int nk = p.K / BK;
@@ -105,192 +204,161 @@ __global__ __launch_bounds__(256, 2) void ld_gemm_kernel(GemmParams p) {
       koffA = (long)kt * BK;
     }
     const long koffW = (long)kt * BK;
-    char* base = smem + buf * STAGE_BYTES;
+    char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(p.A + offA[i] + koffA, base + (wave * 4 + i) * 1024);
-    }
+    for (int i = 0; i < A_LOADS; ++i) glds16(p.A + offA[i] + koffA, base + (wave * A_LOADS + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(p.W + offW[i] + koffW, base + TILE_BYTES + (wave * 4 + i) * 1024);
-    }
+    for (int i = 0; i < B_LOADS; ++i) glds16(p.W + offW[i] + koffW, base + A_BYTES + (wave * B_LOADS + i) * 1024);
   };
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // fragment read addresses (bytes within an operand tile), swizzle key is k-step independent
-  int rdA[2], rdB[2], keyA[2], keyB[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ra = wr * 64 + i * 32 + (lane & 31);
-    const int rb = wc * 64 + i * 32 + (lane & 31);
-    rdA[i] = ra * 128; keyA[i] = (ra >> 1) & 7;
-    rdB[i] = rb * 128; keyB[i] = (rb >> 1) & 7;
-  }
-  const int khalf = lane >> 5;
-
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and releases the other buffer
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* sa = smem + cur * STAGE_BYTES;
-    const char* sb = sa + TILE_BYTES;
+  // fragment read offsets: row * 128 B plus the swizzled 16-B chunk of k-step kk (rows of later MFMA tiles are
+  // +32 rows = +4096 B with the same swizzle key, so they fold into the ds_read immediate offset)
+  int rdA[4], rdB[4];
+  {
+    const int ra = wr * (BM / WM) + (lane & 31), rb = wc * (BN / WN) + (lane & 31);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int c = kk * 2 + khalf;
-      bf16x8_t a[2], b[2];
+      const int c = kk * 2 + (lane >> 5);
+      rdA[kk] = ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4);
+      rdB[kk] = A_BYTES + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4);
+    }
+  }
+
+  auto compute = [&](auto bufc) {
+    constexpr int OFF = decltype(bufc)::value * STAGE;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *(const bf16x8_t*)(sa + rdA[i] + ((c ^ keyA[i]) << 4));
-        b[i] = *(const bf16x8_t*)(sb + rdB[i] + ((c ^ keyB[i]) << 4));
-      }
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8_t a[MI], b[NI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8_t*)(smem + rdA[kk] + OFF + i * 4096);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NI; ++j) b[j] = *(const bf16x8_t*)(smem + rdB[kk] + OFF + j * 4096);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+  };
+
+  if (NSTAGE == 2) {
+    // two K-tiles per trip with compile-time buffer indices; no mid-loop exit (a `break` between the two halves makes
+    // hipcc keep two copies of the 64 accumulator registers and shuffle them every trip), odd tail peeled
+    stage(0, 0);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and releases the other buffer
+      stage(1, kt + 1);
+      compute(std::integral_constant<int, 0>{});
+      __syncthreads();
+      if (kt + 2 < nk) stage(0, kt + 2);
+      compute(std::integral_constant<int, 1>{});
+    }
+    if (kt < nk) {
+      __syncthreads();
+      compute(std::integral_constant<int, 0>{});
+    }
+  } else {
+    // 3-deep LDS ring: the K-tile two steps ahead is requested while tile kt is consumed, and the barrier only
+    // waits for tile kt (counted vmcnt: the newest tile's DMA stays in flight across the barrier; a raw s_barrier is
+    // used because __syncthreads would drain vmcnt to 0).  RAW: own vmcnt + barrier; WAR: buffer (kt+2)%3 was last
+    // read by compute(kt-1), which every wave has finished before passing barrier kt.
+    constexpr int LPS = A_LOADS + B_LOADS;       // LDS-DMA instructions per wave per stage
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    auto step = [&](auto bufc, int kt) {
+      constexpr int B = decltype(bufc)::value;
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) stage((B + 2) % 3, kt + 2);
+      compute(bufc);
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 3) {
+      step(std::integral_constant<int, 0>{}, kt);
+      step(std::integral_constant<int, 1>{}, kt + 1);
+      step(std::integral_constant<int, 2>{}, kt + 2);
+    }
+    if (kt < nk) step(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
   }
   __syncthreads();
 
-  // ---- epilogue: accumulators -> wave-private LDS (fp32) -> row-contiguous 16-B stores ----
-  float* cw = (float*)smem + wave * (64 * CW_STRIDE);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int col = j * 32 + (lane & 31);
-        cw[row * CW_STRIDE + col] = acc[i][j][r];
-      }
-  __syncthreads();
-
+  // ---- epilogue: per MFMA row-block, accumulators -> wave-private LDS (fp32) -> row-contiguous 16-B stores ----
+  float* cw = (float*)smem + wave * (32 * CW_STRIDE);
   const bool vec_ok = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) &&
                       (p.resid == nullptr || (p.ldr & 7) == 0) &&
                       (p.mul == nullptr || (p.ldmul & 7) == 0) &&
                       (p.add2 == nullptr || (p.ldadd & 7) == 0);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        cw[row * CW_STRIDE + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+    __syncthreads();
 #pragma unroll 1
-  for (int ps = 0; ps < 8; ++ps) {
-    const int row = ps * 8 + (lane >> 3);
-    const int col0 = (lane & 7) * 8;
-    const int gm = m0 + wr * 64 + row;
-    const int gn0 = n0 + wc * 64 + col0;
-    if (gm >= p.M || gn0 >= p.N) continue;
-    float v[8];
-    {
-      const f32x4_t lo = *(const f32x4_t*)(cw + row * CW_STRIDE + col0);
-      const f32x4_t hi = *(const f32x4_t*)(cw + row * CW_STRIDE + col0 + 4);
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = ps * 8 + (lane >> 3);
+      const int col0 = (lane & 7) * 8;
+      const int gm = m0 + wr * (BM / WM) + i * 32 + row;
+      const int gn0 = n0 + wc * 64 + col0;
+      if (gm < p.M && gn0 < p.N) {
+        float v[8];
+        const f32x4_t lo = *(const f32x4_t*)(cw + row * CW_STRIDE + col0);
+        const f32x4_t hi = *(const f32x4_t*)(cw + row * CW_STRIDE + col0 + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-    }
-    const int nvalid = (p.N - gn0) < 8 ? (p.N - gn0) : 8;
-    const bf16_t* gate_row = nullptr;
-    if (p.gate) {
-      const int b = gm / p.rows_per_batch;
-      const int rin = gm - b * p.rows_per_batch;
-      gate_row = p.gate + b * p.gate_bstride + (rin < p.text_len ? p.gate_off_txt : p.gate_off_img);
-    }
-    if (vec_ok) {
-      float bias[8], mulv[8], gt[8], rs[8], ad[8];
-      if (p.bias) {
-        const u32x4_t bw = *(const u32x4_t*)(p.bias + gn0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { bias[2 * e] = bf_lo(bw[e]); bias[2 * e + 1] = bf_hi(bw[e]); }
-      }
-      if (p.mul) {
-        const u32x4_t mw = *(const u32x4_t*)(p.mul + (long)gm * p.ldmul + gn0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { mulv[2 * e] = bf_lo(mw[e]); mulv[2 * e + 1] = bf_hi(mw[e]); }
-      }
-      if (gate_row) {
-        const u32x4_t gw = *(const u32x4_t*)(gate_row + gn0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { gt[2 * e] = bf_lo(gw[e]); gt[2 * e + 1] = bf_hi(gw[e]); }
-      }
-      if (p.resid) {
-        if (p.resid_f32) {
-          const f32x4_t r0 = *(const f32x4_t*)((const float*)p.resid + (long)gm * p.ldr + gn0);
-          const f32x4_t r1 = *(const f32x4_t*)((const float*)p.resid + (long)gm * p.ldr + gn0 + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { rs[e] = r0[e]; rs[4 + e] = r1[e]; }
-        } else {
-          const u32x4_t rw = *(const u32x4_t*)((const bf16_t*)p.resid + (long)gm * p.ldr + gn0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { rs[2 * e] = bf_lo(rw[e]); rs[2 * e + 1] = bf_hi(rw[e]); }
-        }
-      }
-      if (p.add2) {
-        const u32x4_t aw = *(const u32x4_t*)(p.add2 + (long)gm * p.ldadd + gn0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ad[2 * e] = bf_lo(aw[e]); ad[2 * e + 1] = bf_hi(aw[e]); }
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = v[e];
-        if (p.bias) x += bias[e];
-        x = rbf(x);                                   // bf16 Linear/conv output
-        if (p.act) x = rbf(apply_act(p.act, x));
-        if (p.mul) x = rbf(x * mulv[e]);
-        if (gate_row) x = rbf(x * gt[e]);
-        if (p.resid) { x = rs[e] + x; if (!p.out_f32) x = rbf(x); }
-        if (p.add2) { x = x + ad[e]; if (!p.out_f32) x = rbf(x); }
-        v[e] = x;
-      }
-      if (p.out_f32) {
-        float* o = (float*)p.out + (long)gm * p.ldo + gn0;
-        *(f32x4_t*)o = (f32x4_t){v[0], v[1], v[2], v[3]};
-        *(f32x4_t*)(o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
-      } else {
-        u32x4_t ow;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ow[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-        *(u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0) = ow;
-      }
-    } else {
-      for (int e = 0; e < nvalid; ++e) {
-        const int gn = gn0 + e;
-        float x = v[e];
-        if (p.bias) x += bf2f(p.bias[gn]);
-        x = rbf(x);
-        if (p.act) x = rbf(apply_act(p.act, x));
-        if (p.mul) x = rbf(x * bf2f(p.mul[(long)gm * p.ldmul + gn]));
-        if (gate_row) x = rbf(x * bf2f(gate_row[gn]));
-        if (p.resid) {
-          const float r = p.resid_f32 ? ((const float*)p.resid)[(long)gm * p.ldr + gn]
-                                      : bf2f(((const bf16_t*)p.resid)[(long)gm * p.ldr + gn]);
-          x = r + x; if (!p.out_f32) x = rbf(x);
-        }
-        if (p.add2) { x = x + bf2f(p.add2[(long)gm * p.ldadd + gn]); if (!p.out_f32) x = rbf(x); }
-        if (p.out_f32) ((float*)p.out)[(long)gm * p.ldo + gn] = x;
-        else ((bf16_t*)p.out)[(long)gm * p.ldo + gn] = f2bf(x);
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+        epilogue_store8(p, v, gm, gn0, vec_ok);
       }
     }
+    __syncthreads();
   }
 }
 
-int launch(const GemmParams& p, bool conv, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
+  constexpr int NW = WM * WN;
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int EPI = NW * 32 * CW_STRIDE * 4;
+  constexpr int SMEM = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  dim3 grid(nbm * nbn), block(256);
+  dim3 grid(nbm * nbn), block(NW * 64);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ld_gemm_kernel<false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)ld_gemm_kernel<true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute((const void*)ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
-  if (conv) hipLaunchKernelGGL(ld_gemm_kernel<true>, grid, block, SMEM_BYTES, stream, p);
-  else hipLaunchKernelGGL(ld_gemm_kernel<false>, grid, block, SMEM_BYTES, stream, p);
+  if (conv) hipLaunchKernelGGL((ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, block, SMEM, stream, p);
+  else hipLaunchKernelGGL((ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, block, SMEM, stream, p);
   return ld_check_launch("ld_gemm");
+}
+
+int launch(const GemmParams& p, bool conv, hipStream_t stream) {
+  // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves / 2 stages, 2 = 256x128 / 8 waves / 2 stages,
+  // 5 = 256x128 / 8 waves / 3-stage counted-vmcnt ring, 6 = 128x128 / 4 waves / 3-stage ring
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("LD_GEMM_TILE"); forced = e ? atoi(e) : 0; }
+  int cfg = forced ? forced : 1;
+  switch (cfg) {
+    case 6: return launch_cfg<128, 128, 2, 2, 3>(p, conv, stream);
+    case 5: return launch_cfg<256, 128, 4, 2, 3>(p, conv, stream);
+    case 2: return launch_cfg<256, 128, 4, 2, 2>(p, conv, stream);
+    default: return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  }
 }
 
 int fill_epilogue(GemmParams& p, const ld_epilogue_t* e) {
