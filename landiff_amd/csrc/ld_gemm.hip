@@ -50,6 +50,7 @@ struct GemmParams {
   long gate_bstride, gate_off_img, gate_off_txt;
   // conv (channels-last, zero-bordered input)
   int H, W_, Hp, Wp, Cin, kH, kW;   // output H,W; padded input Hp,Wp
+  int group_m;                      // tile-raster group height (L2 locality)
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
@@ -161,9 +162,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
 
+  // Tile order: blockIdx -> XCD-contiguous logical id (each XCD has a private 4 MB L2) -> grouped raster: the ~64
+  // tiles resident on one XCD form a GROUP_M x (64/GROUP_M) patch, so an A panel and a W panel are each re-read from
+  // L2 ~8 times instead of W being re-streamed from MALL/HBM for every row of tiles.
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, nbm * nbn);
-  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+  const int gm_sz = p.group_m;
+  const int per_group = gm_sz * nbn;
+  const int group = bid / per_group, in_group = bid - group * per_group;
+  const int first_m = group * gm_sz;
+  const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+  const int m0 = (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
 
   // ---- per-thread source row offsets ----
   uint32_t offA[A_LOADS], offW[B_LOADS];    // element offsets (< 2^31 for every shape on the path)
@@ -350,8 +359,12 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
 int launch(const GemmParams& p, bool conv, hipStream_t stream) {
   // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves / 2 stages, 2 = 256x128 / 8 waves / 2 stages,
   // 5 = 256x128 / 8 waves / 3-stage counted-vmcnt ring, 6 = 128x128 / 4 waves / 3-stage ring
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("LD_GEMM_TILE"); forced = e ? atoi(e) : 0; }
+  static int forced = -1, group_m = 8;
+  if (forced < 0) {
+    const char* e = getenv("LD_GEMM_TILE"); forced = e ? atoi(e) : 0;
+    const char* g = getenv("LD_GEMM_GROUP_M"); if (g && atoi(g) > 0) group_m = atoi(g);
+  }
+  const_cast<GemmParams&>(p).group_m = group_m;
   int cfg = forced ? forced : 1;
   switch (cfg) {
     case 6: return launch_cfg<128, 128, 2, 2, 3>(p, conv, stream);
