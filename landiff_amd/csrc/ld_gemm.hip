@@ -241,20 +241,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
     }
   }
 
+  // One K-tile of MFMAs.  Fragments are software pipelined by hand (k-step kk+1 is requested before the MFMAs of kk)
+  // and a scheduling barrier after every k-step keeps hipcc from hoisting all 4 k-steps' loads at once, which spills
+  // the 128-register accumulator tile of the 256x256 configuration.
   auto compute = [&](auto bufc) {
     constexpr int OFF = decltype(bufc)::value * STAGE;
+    bf16x8_t a[2][MI], b[2][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a[0][i] = *(const bf16x8_t*)(smem + rdA[0] + OFF + i * 4096);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) b[0][j] = *(const bf16x8_t*)(smem + rdB[0] + OFF + j * 4096);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8_t a[MI], b[NI];
+      constexpr int dummy = 0; (void)dummy;
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk < 3) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8_t*)(smem + rdA[kk] + OFF + i * 4096);
+        for (int i = 0; i < MI; ++i) a[nxt][i] = *(const bf16x8_t*)(smem + rdA[kk + 1] + OFF + i * 4096);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = *(const bf16x8_t*)(smem + rdB[kk] + OFF + j * 4096);
+        for (int j = 0; j < NI; ++j) b[nxt][j] = *(const bf16x8_t*)(smem + rdB[kk + 1] + OFF + j * 4096);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      if (MI * NI > 4) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -365,9 +377,16 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     const char* g = getenv("LD_GEMM_GROUP_M"); if (g && atoi(g) > 0) group_m = atoi(g);
   }
   const_cast<GemmParams&>(p).group_m = group_m;
-  int cfg = forced ? forced : 1;
+  // measured on MI355X (tools/microbench.py): the 256x256 tile wins once there are >= ~20 column tiles or a long K
+  // (L2->LDS traffic halves), the 128x128 tile (2 workgroups/CU) wins for narrow outputs and small problems
+  int cfg = forced;
+  if (cfg == 0) {
+    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    cfg = (tiles256 >= 512 && (p.N >= 4096 || p.K >= 4096)) ? 3 : 1;
+  }
   switch (cfg) {
     case 6: return launch_cfg<128, 128, 2, 2, 3>(p, conv, stream);
+    case 3: return launch_cfg<256, 256, 2, 4, 2>(p, conv, stream);
     case 5: return launch_cfg<256, 128, 4, 2, 3>(p, conv, stream);
     case 2: return launch_cfg<256, 128, 4, 2, 2>(p, conv, stream);
     default: return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
