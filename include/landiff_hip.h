@@ -94,10 +94,12 @@ int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
  * bf16 weights: result rounds to bf16 (Linear output), then act, then `* bf16(W2 x)` (gated MLP,
  * LlamaMLP2: landiff/llm/modules/transformer_blocks.py:67-88), then `resid + y`.  w_f32: fp32 weights,
  * x and out fp32 (GPT head, landiff/llm/models/transformer.py:115-118).  in_act is applied to x (bf16-rounded),
- * e.g. the SiLU in front of adaLN_modulation (landiff/diffusion/dit_video_concat.py:499-503). */
+ * e.g. the SiLU in front of adaLN_modulation (landiff/diffusion/dit_video_concat.py:499-503).  norm_w (fp32 [K], optional)
+ * fuses the block's RMSNorm in front of the projection: x -> bf16(x * rsqrt(mean(x^2) + norm_eps) * norm_w). */
 int ld_gemv(const void* x, int64_t ldx, int32_t x_f32, const void* W, const void* W2, int32_t w_f32,
             const void* bias, const void* resid, int64_t ldr, void* out, int64_t ldo, int32_t out_f32,
-            int64_t B, int64_t N, int64_t K, int32_t in_act, int32_t act, void* stream);
+            int64_t B, int64_t N, int64_t K, int32_t in_act, int32_t act, const float* norm_w, float norm_eps,
+            void* stream);
 
 /* RMSNorm (transformer_blocks.py:22-40): bf16 rows [rows][D], fp32 weight, fp32 math, bf16 out. */
 int ld_rmsnorm_bf16(const void* x, const float* w, void* out, int64_t rows, int64_t D, float eps, void* stream);
@@ -114,9 +116,11 @@ int ld_llm_rope_append(const void* qkv, const float* cos_t, const float* sin_t, 
 
 /* Attention of query j (position *pos + j) over keys [0, *pos + j] (transformer_blocks.py:166-186):
  * bf16 scores, bf16(score / sqrt(128)), fp32 softmax -> bf16 p, bf16 output [B][m][H][128].
- * m == 1 with nsplit > 1 uses the key-split path (workspace: B*H*nsplit*130 floats, caller-owned; p kept fp32). */
+ * m == 1 with nsplit > 1 uses the key-split path (workspace: B*H*nsplit*130 floats, caller-owned; p kept fp32); there
+ * qkv_fused ([B][3][H][128], q may be NULL) makes the kernel do apply_rope and the KV append of the new token itself. */
 int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
-                   int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit, void* stream);
+                   int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit,
+                   const void* qkv_fused, const float* cos_t, const float* sin_t, void* stream);
 
 /* nn.Embedding lookup of *token (fp32 table [V][D]) -> bf16 features [B][D] (landiff/llm/modules/tokenizer.py:10-55). */
 int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B, int64_t D, void* stream);

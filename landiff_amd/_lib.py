@@ -49,11 +49,11 @@ SIGNATURES: dict[str, list] = {
     "ld_gemm_bf16": [P, I64, P, P, I64, I64, I64, I64, POINTER(Epilogue), P],
     "ld_conv_cl_bf16": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, POINTER(Epilogue), P],
     "ld_attn_fwd_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_float, P, P, P, P, P],
-    "ld_gemv": [P, I64, I32, P, P, I32, P, P, I64, P, I64, I32, I64, I64, I64, I32, I32, P],
+    "ld_gemv": [P, I64, I32, P, P, I32, P, P, I64, P, I64, I32, I64, I64, I64, I32, I32, P, c_float, P],
     "ld_rmsnorm_bf16": [P, P, P, I64, I64, c_float, P],
     "ld_layernorm_bf16_to_f32": [P, I64, P, P, P, I64, I64, c_float, P],
     "ld_llm_rope_append": [P, P, P, P, P, P, P, I64, I64, I64, I64, P],
-    "ld_llm_kv_attn": [P, P, P, P, P, I64, I64, I64, I64, P, I64, P],
+    "ld_llm_kv_attn": [P, P, P, P, P, I64, I64, I64, I64, P, I64, P, P, P, P],
     "ld_llm_embed": [P, P, P, I64, I64, P],
     "ld_llm_logits_to_probs": [P, P, P, I64, I32, c_float, c_float, P, P, I64, P],
     "ld_llm_decode_advance": [P, P, P, P, P, P, P],

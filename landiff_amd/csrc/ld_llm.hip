@@ -32,78 +32,215 @@ struct GemvParams {
   long ldx, ldo, ldr;
   int x_f32, w_f32, out_f32;
   int in_act, act;
+  const float* norm_w;  // optional fused RMSNorm of x (bf16 x only): xn = bf16(x * rsqrt(mean(x^2)+eps) * norm_w)
+  float norm_eps;
 };
 
-template <int B, bool WF32>
+// Weight-streaming GEMV.  One workgroup = 4 waves x R rows.  The activation rows (B x K, optionally RMS-normalised,
+// optionally passed through in_act) are staged ONCE per workgroup in LDS as bf16/fp32 -- letting every wave re-read x
+// from L2 made all CUs hammer the same few cache lines -- and the first trip's weight loads are issued BEFORE the
+// staging so the HBM latency of the weights overlaps it.  Each lane keeps R*U 16-byte weight loads in flight.
+template <int B, bool WF32, int R>
 __global__ __launch_bounds__(256) void ld_gemv_kernel(GemvParams p) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= p.N) return;
-  float acc[B], acc2[B];
+  constexpr int U = 4;
+  extern __shared__ __attribute__((aligned(16))) char gsm[];   // x staged: [B][K] (bf16, or f32 when WF32) + 64 B scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool gated = !WF32 && p.W2 != nullptr;       // gated form runs with R == 1: rows n0 of W and of W2
+  const int nchunk = p.K >> 3;                       // 8 elements per chunk
+  const int nrow = p.N;
+
+  // work item = (row group, K trip); a wave walks its items in order, always holding the NEXT item's weight vectors
+  // in registers (raw 16-byte loads, converted to fp32 only when consumed)
+  const int ntrip = (nchunk + 64 * U - 1) / (64 * U);
+  const int ngroups = (nrow + R - 1) / R;
+  const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+  auto load_w = [&](u32x4_t (&w)[R][U], u32x4_t (&w2)[U], int grp, int trip) {
+    const int c0 = lane + trip * 64 * U;
 #pragma unroll
-  for (int b = 0; b < B; ++b) { acc[b] = 0.f; acc2[b] = 0.f; }
-  const int nchunk = p.K >> 3;   // 8 elements per chunk
-  for (int c = lane; c < nchunk; c += 64) {
-    float w[8], w2[8];
-    if (WF32) {
-      const f32x4_t a = *(const f32x4_t*)((const float*)p.W + (long)n * p.K + c * 8);
-      const f32x4_t b4 = *(const f32x4_t*)((const float*)p.W + (long)n * p.K + c * 8 + 4);
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 64 * u;
+      const bool ok = (c < nchunk) && (grp < ngroups);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { w[e] = a[e]; w[4 + e] = b4[e]; }
-    } else {
-      const u32x4_t a = __builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)p.W + (long)n * p.K + c * 8));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { w[2 * e] = bf_lo(a[e]); w[2 * e + 1] = bf_hi(a[e]); }
-      if (p.W2) {
-        const u32x4_t a2 = __builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)p.W2 + (long)n * p.K + c * 8));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { w2[2 * e] = bf_lo(a2[e]); w2[2 * e + 1] = bf_hi(a2[e]); }
+      for (int r = 0; r < R; ++r) {
+        const int n = (grp * R + r < nrow) ? grp * R + r : nrow - 1;
+        w[r][u] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (ok) {
+          if (WF32) {
+            // fp32 weights: two 16-byte halves are fetched at use time (head GEMV only; not worth double buffering)
+          } else {
+            w[r][u] = __builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)p.W + (long)n * p.K + c * 8));
+          }
+        }
+      }
+      if (gated) {
+        const int n = (grp < nrow) ? grp : nrow - 1;
+        w2[u] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (ok) w2[u] = __builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)p.W2 + (long)n * p.K + c * 8));
       }
     }
+  };
+
+  u32x4_t wn[R][U], w2n[U];
+  int grp = wave_global, trip = 0;
+  load_w(wn, w2n, grp, trip);                        // first item in flight while x is staged
+
+  // ---- stage x (with the optional fused RMSNorm / input activation) ----
+  float* red = (float*)(gsm + (size_t)B * p.K * (WF32 ? 4 : 2));
+  float rs[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) rs[b] = 1.f;
+  if (p.norm_w) {                                    // RMSNorm scale per row (transformer_blocks.py:22-40)
+    float ss[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-      float xv[8];
-      if (p.x_f32) {
-        const f32x4_t a = *(const f32x4_t*)((const float*)p.x + b * p.ldx + c * 8);
-        const f32x4_t b4 = *(const f32x4_t*)((const float*)p.x + b * p.ldx + c * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { xv[e] = a[e]; xv[4 + e] = b4[e]; }
-      } else {
+      ss[b] = 0.f;
+      for (int c = tid; c < nchunk; c += 256) {
         const u32x4_t a = *(const u32x4_t*)((const bf16_t*)p.x + b * p.ldx + c * 8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { xv[2 * e] = bf_lo(a[e]); xv[2 * e + 1] = bf_hi(a[e]); }
+        for (int e = 0; e < 4; ++e) { const float lo = bf_lo(a[e]), hi = bf_hi(a[e]); ss[b] += lo * lo + hi * hi; }
       }
-      if (p.in_act) {
+      ss[b] = wave_sum(ss[b]);
+      if (lane == 0) red[wave * B + b] = ss[b];
+    }
+    __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xv[e] = rbf(apply_act(p.in_act, xv[e]));
-      }
+    for (int b = 0; b < B; ++b)
+      rs[b] = rsqrtf((red[b] + red[B + b] + red[2 * B + b] + red[3 * B + b]) / (float)p.K + p.norm_eps);
+  }
+  for (int i = tid; i < B * nchunk; i += 256) {
+    const int b = i / nchunk, c = i - b * nchunk;
+    float xv[8];
+    if (p.x_f32) {
+      const f32x4_t a = *(const f32x4_t*)((const float*)p.x + b * p.ldx + c * 8);
+      const f32x4_t b4 = *(const f32x4_t*)((const float*)p.x + b * p.ldx + c * 8 + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[b] = fmaf(xv[e], w[e], acc[b]);
-      if (!WF32 && p.W2) {
+      for (int e = 0; e < 4; ++e) { xv[e] = a[e]; xv[4 + e] = b4[e]; }
+    } else {
+      const u32x4_t a = *(const u32x4_t*)((const bf16_t*)p.x + b * p.ldx + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc2[b] = fmaf(xv[e], w2[e], acc2[b]);
-      }
+      for (int e = 0; e < 4; ++e) { xv[2 * e] = bf_lo(a[e]); xv[2 * e + 1] = bf_hi(a[e]); }
+    }
+    if (p.in_act) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = rbf(apply_act(p.in_act, xv[e]));
+    }
+    if (p.norm_w) {
+      const f32x4_t g0 = *(const f32x4_t*)(p.norm_w + c * 8), g1 = *(const f32x4_t*)(p.norm_w + c * 8 + 4);
+      float r1 = rs[0];
+#pragma unroll
+      for (int bb = 1; bb < B; ++bb) r1 = (b == bb) ? rs[bb] : r1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xv[e] = xv[e] * r1 * g0[e]; xv[4 + e] = xv[4 + e] * r1 * g1[e]; }
+    }
+    if (WF32) {
+      float* d = (float*)gsm + (long)b * p.K + c * 8;
+      *(f32x4_t*)d = (f32x4_t){xv[0], xv[1], xv[2], xv[3]};
+      *(f32x4_t*)(d + 4) = (f32x4_t){xv[4], xv[5], xv[6], xv[7]};
+    } else {
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(xv[2 * e], xv[2 * e + 1]);     // bf16 rounding of the normed x
+      *(u32x4_t*)((bf16_t*)gsm + (long)b * p.K + c * 8) = o;
     }
   }
+  __syncthreads();
+
+  float acc[R][B], acc2[B];
+  while (grp < ngroups) {
+    u32x4_t wc[R][U], w2c[U];
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
-    acc[b] = wave_sum(acc[b]);
-    if (!WF32 && p.W2) acc2[b] = wave_sum(acc2[b]);
-  }
-  if (lane == 0) {
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      float v = acc[b];
-      if (p.bias) v += bf2f(p.bias[n]);
-      if (!WF32) v = rbf(v);                         // bf16 Linear output
-      if (p.act) v = rbf(apply_act(p.act, v));
-      if (!WF32 && p.W2) v = rbf(v * rbf(acc2[b]));
-      if (p.resid) {
-        if (p.out_f32) v = ((const float*)p.resid)[b * p.ldr + n] + v;
-        else v = rbf(bf2f(((const bf16_t*)p.resid)[b * p.ldr + n]) + v);
+      for (int r = 0; r < R; ++r) wc[r][u] = wn[r][u];
+      w2c[u] = w2n[u];
+    }
+    const int cgrp = grp, ctrip = trip;
+    if (++trip == ntrip) { trip = 0; grp += nwaves; }
+    load_w(wn, w2n, grp, trip);                       // prefetch the next item
+    if (ctrip == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc2[b] = 0.f;
+    }
+    const int c0 = lane + ctrip * 64 * U;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 64 * u;
+      if (c >= nchunk) continue;
+      float wf[R][8], w2f[8];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (WF32) {
+          const int n = (cgrp * R + r < nrow) ? cgrp * R + r : nrow - 1;
+          const f32x4_t a = *(const f32x4_t*)((const float*)p.W + (long)n * p.K + c * 8);
+          const f32x4_t b4 = *(const f32x4_t*)((const float*)p.W + (long)n * p.K + c * 8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { wf[r][e] = a[e]; wf[r][4 + e] = b4[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { wf[r][2 * e] = bf_lo(wc[r][u][e]); wf[r][2 * e + 1] = bf_hi(wc[r][u][e]); }
+        }
       }
-      if (p.out_f32) ((float*)p.out)[b * p.ldo + n] = v;
-      else ((bf16_t*)p.out)[b * p.ldo + n] = f2bf(v);
+      if (gated) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { w2f[2 * e] = bf_lo(w2c[u][e]); w2f[2 * e + 1] = bf_hi(w2c[u][e]); }
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float xv[8];
+        if (WF32) {
+          const float* d = (const float*)gsm + (long)b * p.K + c * 8;
+          const f32x4_t a = *(const f32x4_t*)d, b4 = *(const f32x4_t*)(d + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xv[e] = a[e]; xv[4 + e] = b4[e]; }
+        } else {
+          const u32x4_t a = *(const u32x4_t*)((const bf16_t*)gsm + (long)b * p.K + c * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xv[2 * e] = bf_lo(a[e]); xv[2 * e + 1] = bf_hi(a[e]); }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[r][b] = fmaf(xv[e], wf[r][e], acc[r][b]);
+        if (gated) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc2[b] = fmaf(xv[e], w2f[e], acc2[b]);
+        }
+      }
+    }
+    if (ctrip == ntrip - 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
+      if (gated) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc2[b] = wave_sum(acc2[b]);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int n = cgrp * R + r;
+          if (n >= nrow) break;
+#pragma unroll
+          for (int b = 0; b < B; ++b) {
+            float v = acc[r][b];
+            if (p.bias) v += bf2f(p.bias[n]);
+            if (!WF32) v = rbf(v);                         // bf16 Linear output
+            if (p.act) v = rbf(apply_act(p.act, v));
+            if (gated) v = rbf(v * rbf(acc2[b]));
+            if (p.resid) {
+              if (p.out_f32) v = ((const float*)p.resid)[b * p.ldr + n] + v;
+              else v = rbf(bf2f(((const bf16_t*)p.resid)[b * p.ldr + n]) + v);
+            }
+            if (p.out_f32) ((float*)p.out)[b * p.ldo + n] = v;
+            else ((bf16_t*)p.out)[b * p.ldo + n] = f2bf(v);
+          }
+        }
+      }
     }
   }
 }
@@ -256,7 +393,11 @@ __global__ __launch_bounds__(256) void ld_kv_attn_kernel(const bf16_t* q, const 
 // every K/V row is read once with 16-byte loads.  (p stays fp32 here; the reference rounds the normalised p to
 // bf16 before the PV product -- a <= 2^-9 relative, zero-mean difference per term.)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, const bf16_t* kc, const bf16_t* vc,
+// If qkv != nullptr the kernel also does apply_rope + the KV append of the current token itself (q is then ignored):
+// every workgroup rotates q on the fly; the workgroup whose key range holds position *pos rotates/stores the new k
+// and v into the cache before using them.
+__global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, const bf16_t* qkv, const float* cos_t,
+                                                               const float* sin_t, bf16_t* kc, bf16_t* vc,
                                                                const int* pos_ptr, float* ws, int B, int H, int Lmax, int nsplit) {
   extern __shared__ float sc[];       // [chunk] scores + reductions
   const int D = 128;
@@ -275,9 +416,30 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
     if (tid == 0) { out_ws[0] = -3.0e38f; out_ws[1] = 0.f; }
     return;
   }
-  const bf16_t* qv = q + ((long)b * H + h) * D;
   float qreg[8];
-  {
+  if (qkv) {
+    const int pos = L - 1;
+    const bf16_t* src = qkv + ((long)b * 3 * H + h) * D;      // [B][3][H][128]: q at +0, k at +H*D, v at +2*H*D
+    if (pos >= k_begin && pos < k_end && tid < 64) {          // this workgroup owns the new key: append it (one wave)
+      const float c = cos_t[pos * 64 + tid], sn = sin_t[pos * 64 + tid];
+      const float ka = bf2f(src[(long)H * D + 2 * tid]), kb = bf2f(src[(long)H * D + 2 * tid + 1]);
+      const long co = (((long)b * Lmax + pos) * H + h) * D + 2 * tid;
+      kc[co] = f2bf(ka * c - kb * sn);
+      kc[co + 1] = f2bf(ka * sn + kb * c);
+      vc[co] = src[2L * H * D + 2 * tid];
+      vc[co + 1] = src[2L * H * D + 2 * tid + 1];
+    }
+    const u32x4_t a = *(const u32x4_t*)(src + sub * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float c = cos_t[pos * 64 + sub * 4 + e], sn = sin_t[pos * 64 + sub * 4 + e];
+      const float qa = bf_lo(a[e]), qb = bf_hi(a[e]);
+      qreg[2 * e] = rbf(qa * c - qb * sn);
+      qreg[2 * e + 1] = rbf(qa * sn + qb * c);
+    }
+    __syncthreads();                                           // the appended k/v row is read below by this workgroup
+  } else {
+    const bf16_t* qv = q + ((long)b * H + h) * D;
     const u32x4_t a = *(const u32x4_t*)(qv + sub * 8);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { qreg[2 * e] = bf_lo(a[e]); qreg[2 * e + 1] = bf_hi(a[e]); }
@@ -411,28 +573,46 @@ __global__ void ld_decode_advance_kernel(const long* sampled, const int* forced,
   *pos_ptr = pos + 1;
 }
 
+template <int B, bool WF32, int R>
+int launch_gemv_cfg(const GemvParams& p, hipStream_t st) {
+  const size_t smem = (size_t)B * p.K * (WF32 ? 4 : 2) + 64;
+  static size_t attr = 48 * 1024;
+  if (smem > attr) {
+    (void)hipFuncSetAttribute((const void*)ld_gemv_kernel<B, WF32, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = smem;
+  }
+  // persistent grid: ~2 workgroups per CU (or fewer when there are not enough rows); every wave loops over row groups
+  long blocks = (p.N + 4 * R - 1) / (4 * R);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL((ld_gemv_kernel<B, WF32, R>), dim3((unsigned)blocks), dim3(256), smem, st, p);
+  return ld_check_launch("ld_gemv");
+}
+
 template <int B>
 int launch_gemv_b(const GemvParams& p, hipStream_t st) {
-  dim3 grid((p.N + 3) / 4), block(256);
-  if (p.w_f32) hipLaunchKernelGGL((ld_gemv_kernel<B, true>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((ld_gemv_kernel<B, false>), grid, block, 0, st, p);
-  return ld_check_launch("ld_gemv");
+  if (p.w_f32) return launch_gemv_cfg<B, true, 1>(p, st);
+  if (p.W2 || p.N < 4096) return launch_gemv_cfg<B, false, 1>(p, st);   // gated MLP, or few rows: keep all 256 CUs busy
+  return launch_gemv_cfg<B, false, 2>(p, st);
 }
 
 }  // namespace
 
 LD_API int ld_gemv(const void* x, int64_t ldx, int32_t x_f32, const void* W, const void* W2, int32_t w_f32,
                    const void* bias, const void* resid, int64_t ldr, void* out, int64_t ldo, int32_t out_f32,
-                   int64_t B, int64_t N, int64_t K, int32_t in_act, int32_t act, void* stream) {
+                   int64_t B, int64_t N, int64_t K, int32_t in_act, int32_t act, const float* norm_w, float norm_eps,
+                   void* stream) {
   LD_REQUIRE(x && W && out, "ld_gemv: null pointer");
   LD_REQUIRE(B >= 1 && B <= MAXB, "ld_gemv: batch %ld not in [1,%d]", (long)B, MAXB);
   LD_REQUIRE(K % 8 == 0 && ldx % 8 == 0, "ld_gemv: K and ldx must be multiples of 8");
+  LD_REQUIRE((size_t)B * K * (w_f32 ? 4 : 2) + 64 <= 160 * 1024, "ld_gemv: B*K too large for the LDS-staged activations");
   LD_REQUIRE(!(w_f32 && W2), "ld_gemv: gated form needs bf16 weights");
   LD_REQUIRE(!w_f32 || (x_f32 && out_f32), "ld_gemv: fp32 weights need fp32 in/out");
   GemvParams p{};
   p.x = x; p.W = W; p.W2 = W2; p.bias = (const bf16_t*)bias; p.resid = resid; p.out = out;
   p.B = (int)B; p.N = (int)N; p.K = (int)K; p.ldx = ldx; p.ldo = ldo; p.ldr = ldr;
   p.x_f32 = x_f32; p.w_f32 = w_f32; p.out_f32 = out_f32; p.in_act = in_act; p.act = act;
+  p.norm_w = norm_w; p.norm_eps = norm_eps;
+  LD_REQUIRE(!norm_w || (!x_f32 && !w_f32), "ld_gemv: fused RMSNorm needs bf16 x and weights");
   hipStream_t st = (hipStream_t)stream;
   switch (B) {
     case 1: return launch_gemv_b<1>(p, st);
@@ -469,19 +649,23 @@ LD_API int ld_llm_rope_append(const void* qkv, const float* cos_t, const float* 
 }
 
 LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
-                          int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit, void* stream) {
-  LD_REQUIRE(q && k_cache && v_cache && pos && out, "ld_llm_kv_attn: null pointer");
+                          int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit,
+                          const void* qkv_fused, const float* cos_t, const float* sin_t, void* stream) {
+  LD_REQUIRE(k_cache && v_cache && pos && out, "ld_llm_kv_attn: null pointer");
+  LD_REQUIRE(q || qkv_fused, "ld_llm_kv_attn: need q or qkv_fused");
   hipStream_t st = (hipStream_t)stream;
   if (m == 1 && nsplit > 1) {
     LD_REQUIRE(workspace, "ld_llm_kv_attn: split path needs a workspace of B*H*nsplit*130 floats");
+    LD_REQUIRE(!qkv_fused || (cos_t && sin_t), "ld_llm_kv_attn: fused RoPE needs the cos/sin tables");
     const size_t chunk = (size_t)((Lmax + nsplit - 1) / nsplit + 16);
     const size_t smem = (chunk + 8 + 4 * 128) * sizeof(float);
     hipLaunchKernelGGL(ld_kv_attn_split_kernel, dim3((unsigned)(B * H), (unsigned)nsplit), dim3(256), smem, st,
-                       (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, (const int*)pos, workspace,
-                       (int)B, (int)H, (int)Lmax, (int)nsplit);
+                       (const bf16_t*)q, (const bf16_t*)qkv_fused, cos_t, sin_t, (bf16_t*)k_cache, (bf16_t*)v_cache,
+                       (const int*)pos, workspace, (int)B, (int)H, (int)Lmax, (int)nsplit);
     hipLaunchKernelGGL(ld_kv_attn_combine_kernel, dim3((unsigned)(B * H)), dim3(128), 0, st, workspace, (bf16_t*)out, (int)nsplit);
     return ld_check_launch("ld_llm_kv_attn(split)");
   }
+  LD_REQUIRE(q && !qkv_fused, "ld_llm_kv_attn: the fused RoPE/append form exists only for the decode split path");
   const size_t smem = (size_t)(Lmax + 8 + 256) * sizeof(float);
   LD_REQUIRE(smem <= 160 * 1024, "ld_llm_kv_attn: Lmax=%ld too long for the LDS score buffer", (long)Lmax);
   static size_t attr = 0;

@@ -180,15 +180,12 @@ class LLMRunner:
         """One token: embedding of *token at position *pos -> logits [2, V] (all sizes static: graph-capturable)."""
         c, B = self.cfg, self.B
         ops.llm_embed(self.emb, self.token, self.x)
-        for i, w in enumerate(self.blocks):
-            ops.rmsnorm(self.x, w["n0"], self.xn, c.rms_eps)
-            ops.gemv(self.xn, w["wqkv"], self.qkv)
-            ops.llm_rope_append(self.qkv, self.cos, self.sin, self.pos, self.qr, self.kc[i], self.vc[i], B, 1, c.heads, self.Lmax)
-            ops.llm_kv_attn(self.qr, self.kc[i], self.vc[i], self.pos, self.att, B, 1, c.heads, self.Lmax,
-                            workspace=self.attn_ws, nsplit=self.nsplit)
+        for i, w in enumerate(self.blocks):      # 6 launches per layer: RMSNorm rides in the GEMVs, RoPE/append in attention
+            ops.gemv(self.x, w["wqkv"], self.qkv, norm_w=w["n0"], norm_eps=c.rms_eps)
+            ops.llm_kv_attn(None, self.kc[i], self.vc[i], self.pos, self.att, B, 1, c.heads, self.Lmax,
+                            workspace=self.attn_ws, nsplit=self.nsplit, qkv_fused=self.qkv, cos_t=self.cos, sin_t=self.sin)
             ops.gemv(self.att, w["wo"], self.x, resid=self.x)
-            ops.rmsnorm(self.x, w["n1"], self.xn, c.rms_eps)
-            ops.gemv(self.xn, w["w1"], self.gate, w2=w["w3"], act="gelu_tanh")
+            ops.gemv(self.x, w["w1"], self.gate, w2=w["w3"], act="gelu_tanh", norm_w=w["n1"], norm_eps=c.rms_eps)
             ops.gemv(self.gate, w["w2"], self.x, resid=self.x)
         ops.layernorm_bf16_to_f32(self.x, self.ln_w, self.ln_b, self.lnf, c.ln_eps)
         ops.gemv(self.lnf, self.head, self.logits)

@@ -124,7 +124,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tens
 # ------------------------------------------------------------------------------------------------
 # small-batch / LLM kernels
 # ------------------------------------------------------------------------------------------------
-def gemv(x, w, out, *, w2=None, bias=None, resid=None, in_act=None, act=None):
+def gemv(x, w, out, *, w2=None, bias=None, resid=None, in_act=None, act=None, norm_w=None, norm_eps=0.0):
     """out[B,N] = epi(x[B,K] @ w[N,K]^T) for B <= 4 (weight streaming)."""
     B, K = x.shape
     N = w.shape[0]
@@ -133,7 +133,8 @@ def gemv(x, w, out, *, w2=None, bias=None, resid=None, in_act=None, act=None):
     lib = _lib.load()
     check(lib.ld_gemv(_ptr(x), x.stride(0), int(x.dtype == torch.float32), _ptr(w), _ptr(w2), int(w_f32), _ptr(bias),
                       _ptr(resid), resid.stride(0) if resid is not None else 0, _ptr(out), out.stride(0),
-                      int(out.dtype == torch.float32), B, N, K, ACT[in_act], ACT[act], _stream()), "ld_gemv")
+                      int(out.dtype == torch.float32), B, N, K, ACT[in_act], ACT[act], _ptr(norm_w), float(norm_eps),
+                      _stream()), "ld_gemv")
     return out
 
 
@@ -157,9 +158,11 @@ def llm_rope_append(qkv, cos_t, sin_t, pos, q_out, k_cache, v_cache, B, m, H, Lm
                                          _ptr(v_cache), B, m, H, Lmax, _stream()), "ld_llm_rope_append")
 
 
-def llm_kv_attn(q, k_cache, v_cache, pos, out, B, m, H, Lmax, workspace=None, nsplit=1):
+def llm_kv_attn(q, k_cache, v_cache, pos, out, B, m, H, Lmax, workspace=None, nsplit=1, qkv_fused=None, cos_t=None,
+                sin_t=None):
     check(_lib.load().ld_llm_kv_attn(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(pos), _ptr(out), B, m, H, Lmax,
-                                     _ptr(workspace), nsplit, _stream()), "ld_llm_kv_attn")
+                                     _ptr(workspace), nsplit, _ptr(qkv_fused), _ptr(cos_t), _ptr(sin_t), _stream()),
+          "ld_llm_kv_attn")
 
 
 def llm_embed(table, token, out):
