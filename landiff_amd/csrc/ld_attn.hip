@@ -79,8 +79,8 @@ __device__ __forceinline__ int swap23(int i) {
   return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
 
-template <int TPS, bool DEFER, bool PRIO>   // 64-key tiles per LDS stage (per barrier)
-__global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
+template <int TPS, bool DEFER, bool PRIO, bool MFMASUM>   // 64-key tiles per LDS stage (per barrier)
+__global__ __launch_bounds__(256, MFMASUM ? 2 : 3) void ld_attn_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x TPS x (K 8 KB + V^T 8 KB) + 64 B
   constexpr int STAGE = TPS * STAGE_BYTES;
   const int tid = threadIdx.x;
@@ -122,11 +122,19 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
   }
 
   // ---- Q fragments (B operand of K Q^T): lane = query column, 8 consecutive d per k-step ----
+  // Q is pre-multiplied by softmax_scale*log2(e) (one extra bf16 rounding of q, 2^-9 relative) so that the MFMA
+  // accumulator is directly the exp2 argument: started at -m (running max, log2 units) it needs no per-element FMA.
   bf16x8_t qf[4];
   {
     const bf16_t* qrow = Qb + (long)q * D + hi * 8;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(qrow + kk * 16);
+    for (int kk = 0; kk < 4; ++kk) {
+      const u32x4_t raw = *(const u32x4_t*)(qrow + kk * 16);
+      u32x4_t sc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[e] = pack_bf16x2(bf_lo(raw[e]) * p.c, bf_hi(raw[e]) * p.c);
+      qf[kk] = __builtin_bit_cast(bf16x8_t, sc);
+    }
   }
 
   // ---- LDS-DMA source offsets: waves 0,1 stage K (rows = keys), waves 2,3 stage V^T (rows = d) ----
@@ -175,24 +183,34 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
 
   // fragment read byte offsets within a 64-key tile, one per (row block i, k-step): loop invariant, so the
   // per-tile LDS addressing is just "register + immediate" (the stage/buffer offsets are compile-time constants)
-  int kofs[2][4], vofs[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int key = i * 32 + swap23(lane & 31);
-    const int d = i * 32 + (lane & 31);
+  int kofs[4], vofs[4];       // row block i = 1 is +32 rows = +4096 B with the same swizzle key: an immediate offset
+  {
+    const int key = swap23(lane & 31);
+    const int d = lane & 31;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int c = kk * 2 + hi;
-      kofs[i][kk] = key * 128 + ((c ^ ((key >> 1) & 7)) << 4);
-      vofs[i][kk] = KTILE_BYTES + d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
+      kofs[kk] = key * 128 + ((c ^ ((key >> 1) & 7)) << 4);
+      vofs[kk] = KTILE_BYTES + d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
     }
   }
 
   f32x16_t o[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-  float m = NEG_BIG, lsum = 0.f;
-  const float thr = 8.0f / p.c;     // defer the O rescale while the running max grows by < 2^8 (exp2 domain)
+  // running max m (log2 units) lives negated in a 16-register block that is the C operand of the first QK^T MFMA;
+  // it only changes in the rare rescale branch (deferred: P may grow to 2^THR before we rescale)
+  f32x16_t negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  float lsum = 0.f;
+  // MFMASUM: the softmax denominator comes out of the matrix pipe (an all-ones A fragment times P), not from 32 VALU adds
+  f32x16_t lacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  bool unset = true;                 // no valid key seen yet for this query
+  constexpr float THR = 8.0f;
 
   auto tile = [&](auto bufc, auto jc, int t) {
     constexpr int OFF = decltype(bufc)::value * STAGE + decltype(jc)::value * STAGE_BYTES;
@@ -208,18 +226,17 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
     // ---- S^T = K Q^T: all 8 K fragments are requested up front (one exposed LDS latency per tile, not four);
     //      the first k-step uses the inline-constant 0 as C, so the accumulators are never zeroed by VALU moves ----
     f32x16_t sacc[2];
-    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bf16x8_t kf[2][4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) kf[i][kk] = *(const bf16x8_t*)(smem + kofs[i][kk] + OFF);
+      for (int i = 0; i < 2; ++i) kf[i][kk] = *(const bf16x8_t*)(smem + kofs[kk] + OFF + i * 4096);
     if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][kk], qf[kk], kk == 0 ? zero16 : sacc[i], 0, 0, 0);
+        sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][kk], qf[kk], kk == 0 ? negm : sacc[i], 0, 0, 0);
     }
     if (PRIO) __builtin_amdgcn_s_setprio(0);
     // V^T fragments for the PV product: requested now so their LDS latency hides under the softmax VALU work
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) vf[i][ks] = *(const bf16x8_t*)(smem + vofs[i][ks] + OFF);
+      for (int i = 0; i < 2; ++i) vf[i][ks] = *(const bf16x8_t*)(smem + vofs[ks] + OFF + i * 4096);
     // register r of sacc[i] holds key  t*64 + i*32 + (r>>3)*16 + hi*8 + (r&7)
     if (need_mask) {
 #pragma unroll
@@ -255,26 +272,30 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 2; r < 15; ++r) mx = max3f(mx, sacc[1][r], sacc[0][r + 1]);
     mx = fmaxf(mx, sacc[1][15]);
-    mx = lane32_max(mx);
-    if (!DEFER || !__all(mx - m <= thr)) {   // rare after the first tiles: rescale everything held at the old max
-      const float mnew = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m - mnew) * p.c);
-      m = mnew;
+    mx = lane32_max(mx);            // = max_k(S') - m_old for this query (S' in log2 units)
+    const bool valid = mx > -1.0e29f;                       // at least one unmasked key in this tile
+    if (!__all(!(valid && (unset || mx > (DEFER ? THR : 0.0f))))) {
+      // rare: (re)base the running max.  d = how much m grows for this lane; everything held at the old max scales by 2^-d
+      const float d = valid ? (unset ? mx : fmaxf(mx, 0.0f)) : 0.0f;
+      unset = unset && !valid;
+      const float alpha = __builtin_amdgcn_exp2f(-d);
       lsum *= alpha;
+      if (MFMASUM) lacc[0] *= alpha;                       // only row 0 of the ones-product is ever read
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] -= d;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) { o[i][r] *= alpha; sacc[i][r] -= d; }
     }
-    const float mc = m * p.c;
-    float psum = 0.f;                  // (packed v_pk_fma/v_pk_add were measured slower beside the MFMAs: -3 %)
+    float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[i][r], p.c, -mc));
+        const float pv = __builtin_amdgcn_exp2f(sacc[i][r]);
         sacc[i][r] = pv;
-        psum += pv;
+        if (!MFMASUM) psum += pv;
       }
     lsum += psum;
     // ---- O^T += V^T P^T ----
@@ -288,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
       const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
 #pragma unroll
       for (int i = 0; i < 2; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][ks], pb, o[i], 0, 0, 0);
+      if (MFMASUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, lacc, 0, 0, 0);
     }
     if (PRIO) __builtin_amdgcn_s_setprio(0);
   };
@@ -316,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void ld_attn_kernel(AttnParams p) {
   }
 
   // ---- finalize: O = O^T / l, write bf16 rows ----
-  const float ltot = lane32_sum(lsum);
+  const float ltot = MFMASUM ? lacc[0] : lane32_sum(lsum);
   const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
   if (q < p.Nq) {
     bf16_t* orow = p.O + (long)b * p.o_bs + (long)q * p.o_rs + h * D;
@@ -356,24 +378,12 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   dim3 grid((unsigned)(B * H * nqb)), block(256);
   static int var = -1;
   if (var < 0) {
-    const char* e = getenv("LD_ATTN_VARIANT");     // bit0: TPS=2, bit1: DEFER, bit2: PRIO (tuning knob)
-    var = e ? atoi(e) : 2;                          // default: 1 tile/stage, deferred rescale, no setprio (measured best)
-    (void)hipFuncSetAttribute((const void*)ld_attn_kernel<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES + 64);
-    (void)hipFuncSetAttribute((const void*)ld_attn_kernel<2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES + 64);
-    (void)hipFuncSetAttribute((const void*)ld_attn_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES + 64);
-    (void)hipFuncSetAttribute((const void*)ld_attn_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES + 64);
+    const char* e = getenv("LD_ATTN_VARIANT");     // tuning knob: 0 = VALU row sums, 1 = row sums on the matrix pipe
+    var = e ? atoi(e) : 0;
   }
   hipStream_t st = (hipStream_t)stream;
-  const size_t s1 = 2 * STAGE_BYTES + 64, s2 = 4 * STAGE_BYTES + 64;
-  switch (var & 7) {
-    case 0: hipLaunchKernelGGL((ld_attn_kernel<1, false, false>), grid, block, s1, st, p); break;
-    case 1: hipLaunchKernelGGL((ld_attn_kernel<2, false, false>), grid, block, s2, st, p); break;
-    case 2: hipLaunchKernelGGL((ld_attn_kernel<1, true, false>), grid, block, s1, st, p); break;
-    case 3: hipLaunchKernelGGL((ld_attn_kernel<2, true, false>), grid, block, s2, st, p); break;
-    case 4: hipLaunchKernelGGL((ld_attn_kernel<1, false, true>), grid, block, s1, st, p); break;
-    case 5: hipLaunchKernelGGL((ld_attn_kernel<2, false, true>), grid, block, s2, st, p); break;
-    case 6: hipLaunchKernelGGL((ld_attn_kernel<1, true, true>), grid, block, s1, st, p); break;
-    default: hipLaunchKernelGGL((ld_attn_kernel<2, true, true>), grid, block, s2, st, p); break;
-  }
+  const size_t s1 = 2 * STAGE_BYTES + 64;
+  if (var == 1) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true>), grid, block, s1, st, p);
+  else hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false>), grid, block, s1, st, p);
   return ld_check_launch("ld_attn_fwd_bf16");
 }
