@@ -33,7 +33,7 @@ def cpu_baseline(cfg, budget_s: float = 25.0):
     from oracle.dit import DiTOracle
     from oracle.llm import LLMOracle
     from oracle.tokenizer import DetokenizerOracle, rope3d_table, frame_ids
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)      # torch CPU ops stop scaling (and small ops regress) far below 256 threads
     torch.set_num_threads(cores)
     out = {}
     with torch.no_grad():
@@ -47,10 +47,13 @@ def cpu_baseline(cfg, budget_s: float = 25.0):
         cache = [(torch.randn(2, 1200, l1.heads, l1.head_dim), torch.randn(2, 1200, l1.heads, l1.head_dim)) for _ in range(2)]
         cos, sin = torch.ones(1, 1, l1.head_dim // 2), torch.zeros(1, 1, l1.head_dim // 2)
         x = torch.randn(2, 1, l1.hidden)
-        t0 = time.perf_counter()
-        for i in range(2):
-            x = lo.block(i, x, cache, cos, sin)
-        out["llm_layer_s"] = (time.perf_counter() - t0) / 2
+        def llm_layers():
+            c2 = list(cache)
+            y = x
+            for i in range(2):
+                y = lo.block(i, y, c2, cos, sin)
+        llm_layers()                                     # warm-up (thread pool start-up, first-touch)
+        t0 = time.perf_counter(); llm_layers(); out["llm_layer_s"] = (time.perf_counter() - t0) / 2
         t1 = dataclasses.replace(cfg.tok, layers=1)
         to = DetokenizerOracle(init_state(tokenizer_spec(t1), 3), {}, t1, cfg.ups, torch.float32)
         xt = torch.randn(1, t1.seq_len, t1.width)
@@ -60,6 +63,7 @@ def cpu_baseline(cfg, budget_s: float = 25.0):
         t0 = time.perf_counter(); to.titok_block(0, xt, c3[None], s3[None], mask); out["titok_layer_s"] = time.perf_counter() - t0
         xc = torch.randn(1, 128, 4, 120, 180)
         wc = torch.randn(128, 128, 3, 3, 3)
+        torch.nn.functional.conv3d(xc, wc, padding=(0, 1, 1))      # warm-up
         t0 = time.perf_counter(); torch.nn.functional.conv3d(xc, wc, padding=(0, 1, 1)); dt = time.perf_counter() - t0
         out["conv_tflops"] = 2 * 128 * 128 * 27 * 2 * 120 * 180 / dt / 1e12
     d, l = cfg.dit, cfg.llm
