@@ -79,8 +79,8 @@ __device__ __forceinline__ int swap23(int i) {
   return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
 
-template <int TPS, bool DEFER, bool PRIO, bool MFMASUM>   // 64-key tiles per LDS stage (per barrier)
-__global__ __launch_bounds__(256, MFMASUM ? 2 : 3) void ld_attn_kernel(AttnParams p) {
+template <int TPS, bool DEFER, bool PRIO, bool MFMASUM, int WPS>   // WPS = waves per SIMD the register budget targets
+__global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x TPS x (K 8 KB + V^T 8 KB) + 64 B
   constexpr int STAGE = TPS * STAGE_BYTES;
   const int tid = threadIdx.x;
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256, MFMASUM ? 2 : 3) void ld_attn_kernel(AttnParam
   f32x16_t negm;
 #pragma unroll
   for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  float negm0 = 0.f;                 // scalar copy used by the lean-register (WPS >= 4) form
   float lsum = 0.f;
   // MFMASUM: the softmax denominator comes out of the matrix pipe (an all-ones A fragment times P), not from 32 VALU adds
   f32x16_t lacc;
@@ -226,6 +227,28 @@ __global__ __launch_bounds__(256, MFMASUM ? 2 : 3) void ld_attn_kernel(AttnParam
     // ---- S^T = K Q^T: all 8 K fragments are requested up front (one exposed LDS latency per tile, not four);
     //      the first k-step uses the inline-constant 0 as C, so the accumulators are never zeroed by VALU moves ----
     f32x16_t sacc[2];
+    if (WPS >= 4) {
+      // lean-register form (<= 128 VGPRs, 4 waves/SIMD): C starts at the inline constant 0, K fragments in two halves
+      const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        bf16x8_t kh[2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) kh[i][k2] = *(const bf16x8_t*)(smem + kofs[half * 2 + k2] + OFF + i * 4096);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[i][k2], qf[half * 2 + k2],
+                                                              (half == 0 && k2 == 0) ? zero16 : sacc[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[i][r] += negm0;        // S' - m_old
+    } else {
     bf16x8_t kf[2][4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
@@ -239,12 +262,15 @@ __global__ __launch_bounds__(256, MFMASUM ? 2 : 3) void ld_attn_kernel(AttnParam
         sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][kk], qf[kk], kk == 0 ? negm : sacc[i], 0, 0, 0);
     }
     if (PRIO) __builtin_amdgcn_s_setprio(0);
+    }
     // V^T fragments for the PV product: requested now so their LDS latency hides under the softmax VALU work
     bf16x8_t vf[2][4];
+    if (WPS < 4) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) vf[i][ks] = *(const bf16x8_t*)(smem + vofs[ks] + OFF + i * 4096);
+        for (int i = 0; i < 2; ++i) vf[i][ks] = *(const bf16x8_t*)(smem + vofs[ks] + OFF + i * 4096);
+    }
     // register r of sacc[i] holds key  t*64 + i*32 + (r>>3)*16 + hi*8 + (r&7)
     if (need_mask) {
 #pragma unroll
@@ -281,8 +307,11 @@ __global__ __launch_bounds__(256, MFMASUM ? 2 : 3) void ld_attn_kernel(AttnParam
       const float alpha = __builtin_amdgcn_exp2f(-d);
       lsum *= alpha;
       if (MFMASUM) lacc[0] *= alpha;                       // only row 0 of the ones-product is ever read
+      if (WPS >= 4) negm0 -= d;
+      else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) negm[r] -= d;
+        for (int r = 0; r < 16; ++r) negm[r] -= d;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -308,7 +337,10 @@ __global__ __launch_bounds__(256, MFMASUM ? 2 : 3) void ld_attn_kernel(AttnParam
         pw[e] = pack_bf16x2(sacc[ks >> 1][(ks & 1) * 8 + 2 * e], sacc[ks >> 1][(ks & 1) * 8 + 2 * e + 1]);
       const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][ks], pb, o[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8_t va = (WPS >= 4) ? *(const bf16x8_t*)(smem + vofs[ks] + OFF + i * 4096) : vf[i][ks];
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, o[i], 0, 0, 0);
+      }
       if (MFMASUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, lacc, 0, 0, 0);
     }
     if (PRIO) __builtin_amdgcn_s_setprio(0);
@@ -383,7 +415,8 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   }
   hipStream_t st = (hipStream_t)stream;
   const size_t s1 = 2 * STAGE_BYTES + 64;
-  if (var == 1) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true>), grid, block, s1, st, p);
-  else hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false>), grid, block, s1, st, p);
+  if (var == 1) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);
+  else if (var == 4) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 4>), grid, block, s1, st, p);
+  else hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 3>), grid, block, s1, st, p);
   return ld_check_launch("ld_attn_fwd_bf16");
 }
