@@ -21,17 +21,23 @@ class DiffusionSampler:
         self.plan = build_plan(cfg)
 
     @torch.no_grad()
-    def run(self, denoise_step, noise: torch.Tensor, randn_like=torch.randn_like, prefix=None, trace=None):
+    def run(self, denoise_step, noise: torch.Tensor, randn_like=torch.randn_like, prefix=None, trace=None,
+            fixed_frames: int = 0):
         """denoise_step(x, timestep, c_out, c_skip, cfg_scale, out) -> out (fp32, same shape as x).
-        noise [1,T,C,H,W] fp32 on the device.  `prefix` latents overwrite the first frames (diffusion_video.py:287-288)."""
+        noise [1,T,C,H,W] fp32 on the device.  `prefix` latents overwrite the first frames (diffusion_video.py:287-288);
+        `fixed_frames` > 0 pins the first frames to their initial value before every step and at the end
+        (VPSDEDPMPP2MSampler.__call__, sampling.py:800-835, sdedit=False) -- the streaming primitive."""
         x = noise.clone()
         if prefix is not None:
             x[:, : prefix.shape[1]] = prefix
+        pinned = x[:, :fixed_frames].clone() if fixed_frames > 0 else None
         den = torch.empty_like(x)
         den_d = torch.empty_like(x)
         old = torch.empty_like(x)
         have_old = False
         for sp in self.plan:
+            if pinned is not None:
+                x[:, :fixed_frames] = pinned                    # slab copy (plumbing)
             denoise_step(x, sp.timestep, sp.c_out, sp.c_skip, sp.cfg_scale, den)
             if trace is not None:
                 trace.append((sp.index, sp.timestep, sp.cfg_scale))
@@ -50,4 +56,6 @@ class DiffusionSampler:
                 ops.axpbypcz(x, x, sp.m1, den_d, -sp.m2, n2, sp.m_noise)
             old, den = den, old
             have_old = True
+        if pinned is not None:
+            x[:, :fixed_frames] = pinned
         return x

@@ -124,8 +124,11 @@ def gen_schedule_and_sampler():
         return 0.6 * x * torch.cos(t * 0.01).view(-1, 1, 1, 1, 1) + 0.1 * ctx + 0.05 * torch.sin(x * 3.0)
 
     out = {}
-    for name, cls, n in (("vpsde", VPSDEDPMPP2MSampler, 50), ("vpsde7", VPSDEDPMPP2MSampler, 7), ("ddim", VideoDDIMSampler, 10)):
+    for name, cls, n in (("vpsde", VPSDEDPMPP2MSampler, 50), ("vpsde7", VPSDEDPMPP2MSampler, 7), ("ddim", VideoDDIMSampler, 10),
+                         ("vpsde_fixed2", VPSDEDPMPP2MSampler, 6)):
         smp = make(cls, n)
+        if name == "vpsde_fixed2":          # streaming primitive: the first 2 latent frames are pinned (sampling.py:800-835)
+            smp.fixed_frames = 2
         torch.manual_seed(1234)
         x = torch.randn(1, 3, 4, 4, 6)
         cond = {"crossattn": torch.randn(1, 5, 8)}

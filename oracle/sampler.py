@@ -79,14 +79,17 @@ class DiffusionSamplerOracle:
         scale = dynamic_cfg_scale(c.cfg_scale, c.cfg_exp, c.num_steps, (c.num_steps - timestep).item())
         return x_u + scale * (x_c - x_u), scale
 
-    def run(self, network, x, cond, uc, randn_like=torch.randn_like, trace=None):
+    def run(self, network, x, cond, uc, randn_like=torch.randn_like, trace=None, fixed_frames=0):
         """network(x[2B,...] fp32, idx[2B], ctx[2B,...]) -> eps-like output (any float dtype)."""
         c = self.cfg
         a, ts = self.prepare()
         n = len(a)
         s_in = x.new_ones([x.shape[0]])
         old = None
+        prefix_frames = x[:, :fixed_frames] if fixed_frames > 0 else None     # sampling.py:800-801
         for i in range(n - 1):
+            if fixed_frames > 0:                                              # :803-817 (sdedit=False branch)
+                x = torch.cat([prefix_frames, x[:, fixed_frames:]], dim=1)
             cur, nxt = s_in * a[i], s_in * a[i + 1]
             prev = None if i == 0 else s_in * a[i - 1]
             timestep = ts[-(i + 1)]
@@ -121,6 +124,8 @@ class DiffusionSamplerOracle:
             den_d = _ap(m3, x) * den - _ap(m4, x) * old
             x = _ap(m1, x) * x - _ap(m2, x) * den_d + _ap(mn, x) * randn_like(x)   # second draw (:778)
             old = den
+        if fixed_frames > 0:                                                  # :834-835
+            x = torch.cat([prefix_frames, x[:, fixed_frames:]], dim=1)
         return x
 
 

@@ -82,6 +82,13 @@ def test_sampler_loop_matches_oracle(cuda, setup):
             return out
         res = DiffusionSampler(sc).run(step, x0.to(cuda), randn_like=lambda t: next(it_gpu).to(cuda))
         assert rel(res, ref) < 1e-5, (kind, rel(res, ref))
+    # streaming primitive: pinned prefix frames (sampling.py:800-835)
+    sc = SamplerConfig(num_steps=5)
+    it_cpu, it_gpu = iter(noises), iter(noises)
+    ref = DiffusionSamplerOracle(sc).run(lambda xx, idx, c: 0.5 * xx, x0.clone(), torch.zeros(1, 2, 4), torch.zeros(1, 2, 4),
+                                         randn_like=lambda t: next(it_cpu), fixed_frames=1)
+    res = DiffusionSampler(sc).run(step, x0.to(cuda), randn_like=lambda t: next(it_gpu).to(cuda), fixed_frames=1)
+    assert rel(res, ref) < 1e-5 and torch.equal(res[:, :1].cpu(), x0[:, :1])
 
 
 def test_detokenizer_semantic_condition(cuda, setup):

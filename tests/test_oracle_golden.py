@@ -42,7 +42,8 @@ def test_schedule_tables_bit_exact():
     assert np.array_equal(te.numpy(), g["timestep_embedding"])
 
 
-@pytest.mark.parametrize("name,n,kind", [("vpsde", 50, "vpsde_dpmpp2m"), ("vpsde7", 7, "vpsde_dpmpp2m"), ("ddim", 10, "ddim")])
+@pytest.mark.parametrize("name,n,kind", [("vpsde", 50, "vpsde_dpmpp2m"), ("vpsde7", 7, "vpsde_dpmpp2m"), ("ddim", 10, "ddim"),
+                                         ("vpsde_fixed2", 6, "vpsde_dpmpp2m")])
 def test_sampler_trajectory_bit_exact(name, n, kind):
     from landiff_amd.config import SamplerConfig
     from oracle.sampler import DiffusionSamplerOracle
@@ -57,8 +58,10 @@ def test_sampler_trajectory_bit_exact(name, n, kind):
     x = torch.randn(1, 3, 4, 4, 6)
     cond = torch.randn(1, 5, 8)
     assert np.array_equal(x.numpy(), g[name + "_x0"]) and np.array_equal(cond.numpy(), g[name + "_cond"])
-    out = s.run(network, x.clone(), cond, torch.zeros_like(cond))
+    out = s.run(network, x.clone(), cond, torch.zeros_like(cond), fixed_frames=2 if name == "vpsde_fixed2" else 0)
     assert np.array_equal(out.numpy(), g[name + "_out"])
+    if name == "vpsde_fixed2":
+        assert np.array_equal(out[:, :2].numpy(), g[name + "_x0"][:, :2])      # pinned frames come back untouched
 
 
 # ---------------------------------------------------------------- RoPE / mask
