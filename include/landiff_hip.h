@@ -126,10 +126,13 @@ int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, cons
 int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B, int64_t D, void* stream);
 
 /* lm_model.py:417-454: logits [2][V] = (cond, uncond) -> CFG `u + s*(c-u)` (guided), / temperature, optional
- * restriction to allowed[*pos + 1][1 .. 1+allowed[..][0]], softmax -> probs [V].  cfg_logits (optional) gets the CFG logits. */
+ * restriction to allowed[*pos + 1][1 .. 1+allowed[..][0]], softmax -> probs [V] (V <= 4096).  cfg_logits (optional) gets
+ * the CFG logits.  At unrestricted positions: top_k > 0 keeps logits >= the k-th largest (lm_model.py:441-443), and
+ * top_p >= 0 is top_p_probability (landiff/utils.py:345-359: descending sort, sequential cumsum, drop sorted position
+ * j >= 1 when cumsum[j-1] >= top_p, renormalise).  top_k <= 0 / top_p < 0 switch the filters off (the CLI default). */
 int ld_llm_logits_to_probs(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided,
                            float scale, float temperature, const int32_t* pos, const int32_t* allowed,
-                           int64_t allowed_stride, void* stream);
+                           int64_t allowed_stride, int32_t top_k, float top_p, void* stream);
 
 /* After torch.multinomial: forced-token override (forced[*pos + 1] >= 0), record sampled visual tokens, ++*pos
  * (the elif chain of lm_model.py:455-508). */

@@ -54,13 +54,14 @@ class ArModelInferWrapper(torch.nn.Module):
     @torch.no_grad()
     def forward(self, code_task: CodeTask) -> CodeTask:
         sc = code_task.sample_cfg
-        if sc.top_k is not None or sc.top_p is not None or sc.teacher_forcing or sc.use_gt_first_frame:
-            raise NotImplementedError("top_k/top_p/teacher_forcing/use_gt_first_frame are not on the MI355X path (CLI defaults are off)")
+        if sc.teacher_forcing or sc.use_gt_first_frame:
+            # both need the tokenizer *encoder* half, which is outside the decode path
+            raise NotImplementedError("teacher_forcing/use_gt_first_frame need the tokenizer encoder (CLI defaults are off)")
         text = encode_flan_t5([code_task.prompt], self.device_)[0]
         torch.manual_seed(code_task.seed)
         torch.cuda.manual_seed(code_task.seed)
         tokens = self.runner.sample(text, motion_score=sc.motion_score if sc.motion_score is not None else 0.0,
                                     num_frames=sc.num_frames, guidance_scale=sc.cfg, temperature=sc.temperature,
-                                    seed=code_task.seed)
+                                    seed=code_task.seed, top_k=sc.top_k, top_p=sc.top_p)
         code_task.result = tokens.cpu().reshape(-1)
         return code_task

@@ -518,21 +518,34 @@ __global__ void ld_embed_kernel(const float* table, const long* token, bf16_t* o
   out[i] = f2bf(table[t * D + (i % D)]);
 }
 
-// logits [2][V] (cond, uncond) or [1][V] -> probs [V]: CFG, /temperature, optional restriction, softmax.
-// Single block; V <= a few thousand.  (lm_model.py:417-454)
+// logits [2][V] (cond, uncond) or [1][V] -> probs [V]: CFG, /temperature, optional restriction, optional top-k,
+// softmax, optional top-p.  Single block; V <= LD_SAMPLE_MAXV.  (lm_model.py:417-454, utils.py:345-359)
+#define LD_SAMPLE_MAXV 4096
+__device__ __forceinline__ float block_sum_1024(float v, float* red, int tid, int nthreads) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < (nthreads >> 6); ++w) tot += red[w];
+  return tot;
+}
 __global__ __launch_bounds__(1024) void ld_logits_to_probs_kernel(const float* logits, float* probs, float* cfg_logits,
                                                                   int V, int guided, float scale, float temperature,
-                                                                  const int* pos_ptr, const int* allowed, int n_allowed_stride) {
+                                                                  const int* pos_ptr, const int* allowed, int n_allowed_stride,
+                                                                  int top_k, float top_p) {
   __shared__ float red[32];
-  const int tid = threadIdx.x;
+  __shared__ float sv[LD_SAMPLE_MAXV];     // value per vocabulary id
+  __shared__ float ss[LD_SAMPLE_MAXV];     // values in descending order (top-p)
+  __shared__ float thr_s;
+  const int tid = threadIdx.x, nt = blockDim.x;
   const int* al = nullptr;
   int nal = 0;
   if (allowed) {
     al = allowed + (long)(*pos_ptr + 1) * n_allowed_stride;   // table indexed by the position being generated
     nal = al[0];
   }
-  float mx = -3.0e38f;
-  for (int i = tid; i < V; i += blockDim.x) {
+  for (int i = tid; i < V; i += nt) {
     float l = logits[i];
     if (guided) { const float u = logits[V + i]; l = u + scale * (l - u); }
     if (cfg_logits) cfg_logits[i] = l;
@@ -542,23 +555,63 @@ __global__ __launch_bounds__(1024) void ld_logits_to_probs_kernel(const float* l
       for (int a = 0; a < nal; ++a) ok |= (al[1 + a] == i);
       if (!ok) l = -INFINITY;
     }
-    probs[i] = l;
-    mx = fmaxf(mx, l);
+    sv[i] = l;
   }
+  __syncthreads();
+  // top-k (unrestricted positions only): everything below the k-th largest logit -> -inf; ties at the threshold stay
+  if (top_k > 0 && top_k < V && nal == 0) {
+    for (int i = tid; i < V; i += nt) {
+      const float v = sv[i];
+      int gt = 0, ge = 0;
+      for (int j = 0; j < V; ++j) { const float o = sv[j]; gt += (o > v); ge += (o >= v); }
+      if (gt < top_k && top_k <= ge) thr_s = v;               // every writer holds the same value
+    }
+    __syncthreads();
+    const float thr = thr_s;
+    for (int i = tid; i < V; i += nt) if (sv[i] < thr) sv[i] = -INFINITY;
+    __syncthreads();
+  }
+  float mx = -3.0e38f;
+  for (int i = tid; i < V; i += nt) mx = fmaxf(mx, sv[i]);
   mx = wave_max(mx);
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
   float m2 = red[0];
-  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m2 = fmaxf(m2, red[w]);
-  __syncthreads();
+  for (int w = 1; w < (nt >> 6); ++w) m2 = fmaxf(m2, red[w]);
   float s = 0.f;
-  for (int i = tid; i < V; i += blockDim.x) { const float e = expf(probs[i] - m2); probs[i] = e; s += e; }
-  s = wave_sum(s);
-  if ((tid & 63) == 0) red[tid >> 6] = s;
+  for (int i = tid; i < V; i += nt) { const float e = expf(sv[i] - m2); sv[i] = e; s += e; }
+  const float tot = block_sum_1024(s, red, tid, nt);
+  for (int i = tid; i < V; i += nt) sv[i] = sv[i] / tot;
   __syncthreads();
-  float tot = 0.f;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
-  for (int i = tid; i < V; i += blockDim.x) probs[i] = probs[i] / tot;
+  // top-p (unrestricted positions only): drop sorted position j >= 1 when cumsum[j-1] >= top_p, renormalise
+  if (top_p >= 0.f && nal == 0) {
+    int rk[(LD_SAMPLE_MAXV + 1023) / 1024];
+    int c = 0;
+    for (int i = tid; i < V; i += nt, ++c) {
+      const float v = sv[i];
+      int r = 0;
+      for (int j = 0; j < V; ++j) { const float o = sv[j]; r += (o > v) || (o == v && j < i); }   // stable descending rank
+      rk[c] = r;
+      ss[r] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {                                            // sequential fp32 cumsum (torch.cumsum's CPU order)
+      float acc = 0.f;
+      for (int j = 0; j < V; ++j) { acc += ss[j]; ss[j] = acc; }
+    }
+    __syncthreads();
+    float ks = 0.f;
+    c = 0;
+    for (int i = tid; i < V; i += nt, ++c) {
+      const int r = rk[c];
+      if (r >= 1 && ss[r - 1] >= top_p) sv[i] = 0.f;
+      ks += sv[i];
+    }
+    const float kept = block_sum_1024(ks, red, tid, nt);
+    for (int i = tid; i < V; i += nt) sv[i] = sv[i] / kept;
+    __syncthreads();
+  }
+  for (int i = tid; i < V; i += nt) probs[i] = sv[i];
 }
 
 // after torch.multinomial: apply the forced-token schedule, record the sampled token, advance position
@@ -688,11 +741,12 @@ LD_API int ld_llm_embed(const float* table, const int64_t* token, void* out, int
 
 LD_API int ld_llm_logits_to_probs(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided,
                                   float scale, float temperature, const int32_t* pos, const int32_t* allowed,
-                                  int64_t allowed_stride, void* stream) {
-  LD_REQUIRE(logits && probs && V > 0, "ld_llm_logits_to_probs: bad args");
+                                  int64_t allowed_stride, int32_t top_k, float top_p, void* stream) {
+  LD_REQUIRE(logits && probs && V > 0 && V <= LD_SAMPLE_MAXV, "ld_llm_logits_to_probs: bad args (V=%ld, max %d)", (long)V, LD_SAMPLE_MAXV);
   LD_REQUIRE(!allowed || pos, "ld_llm_logits_to_probs: allowed table needs pos");
   hipLaunchKernelGGL(ld_logits_to_probs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, probs, cfg_logits,
-                     (int)V, guided, scale, temperature, (const int*)pos, (const int*)allowed, (int)allowed_stride);
+                     (int)V, guided, scale, temperature, (const int*)pos, (const int*)allowed, (int)allowed_stride,
+                     (int)top_k, top_p);
   return ld_check_launch("ld_llm_logits_to_probs");
 }
 

@@ -115,6 +115,7 @@ class LLMRunner:
         self.probs = e(1, c.vocab, dt=torch.float32)
         self.cfg_logits = e(1, c.vocab, dt=torch.float32)
         self.nsplit = max(1, 256 // (B * H))
+        self.top_k, self.top_p = None, None
         self.attn_ws = e(B * H * self.nsplit * 130, dt=torch.float32)
         self._graph = None
 
@@ -191,7 +192,8 @@ class LLMRunner:
         ops.gemv(self.lnf, self.head, self.logits)
 
     def _sample_and_advance(self, guided, scale, temperature, generator):
-        ops.llm_logits_to_probs(self.logits, self.probs, self.cfg_logits, guided, scale, temperature, self.pos, self.allowed)
+        ops.llm_logits_to_probs(self.logits, self.probs, self.cfg_logits, guided, scale, temperature, self.pos, self.allowed,
+                                top_k=self.top_k, top_p=self.top_p)
         torch.multinomial(self.probs, num_samples=1, generator=generator, out=self.sampled)
         ops.llm_decode_advance(self.sampled, self.forced, self.pos, self.token, self.out_tokens, self.out_count)
 
@@ -199,10 +201,11 @@ class LLMRunner:
     @torch.no_grad()
     def sample(self, text_emb: torch.Tensor, *, motion_score: float = 0.1, num_frames: int = 13, guidance_scale: float = 7.5,
                temperature: float = 1.0, seed: int | None = None, generator=None, use_graph: bool = True,
-               teacher_fed=None, logits_log=None) -> torch.Tensor:
+               teacher_fed=None, logits_log=None, top_k: int | None = None, top_p: float | None = None) -> torch.Tensor:
         """Returns the clamped visual token ids, int64 [n_visual] on the device (lm_model.py:509-516).
-        top_k / top_p (off by default in the reference CLI) are not implemented on this path."""
+        top_k / top_p filter the unrestricted positions inside the sampling kernel (lm_model.py:441-447)."""
         c, dev = self.cfg, self.dev
+        self.top_k, self.top_p = top_k, top_p
         guided = guidance_scale > 0 and guidance_scale != 1
         assert guided, "the shipped pipeline always runs with CFG (cfg=7.5); unguided decode is not implemented"
         feats = self.prefix_features(text_emb, float(num_frames), motion_score)

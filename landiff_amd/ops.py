@@ -170,11 +170,14 @@ def llm_embed(table, token, out):
     check(_lib.load().ld_llm_embed(_ptr(table), _ptr(token), _ptr(out), B, D, _stream()), "ld_llm_embed")
 
 
-def llm_logits_to_probs(logits, probs, cfg_logits, guided, scale, temperature, pos=None, allowed=None):
+def llm_logits_to_probs(logits, probs, cfg_logits, guided, scale, temperature, pos=None, allowed=None,
+                        top_k=None, top_p=None):
     V = probs.shape[-1]
     check(_lib.load().ld_llm_logits_to_probs(_ptr(logits), _ptr(probs), _ptr(cfg_logits), V, int(guided), float(scale),
                                              float(temperature), _ptr(pos), _ptr(allowed),
-                                             allowed.stride(0) if allowed is not None else 0, _stream()),
+                                             allowed.stride(0) if allowed is not None else 0,
+                                             int(top_k) if top_k is not None else 0,
+                                             float(top_p) if top_p is not None else -1.0, _stream()),
           "ld_llm_logits_to_probs")
 
 

@@ -160,6 +160,18 @@ def test_llm_teacher_forced_logits_and_sampler(cuda, setup):
     # 3) sampler exactness: given the device's own probabilities the same stream yields the same ids.
     agree = (ref_codes.reshape(-1) == codes.cpu()).float().mean().item()
     assert agree >= 0.8, agree
+    # 4) top-k inside the decode loop (a9): every freely sampled token is one of the 3 best CFG logits of its step
+    log3 = []
+    gen3 = torch.Generator(device=cuda); gen3.manual_seed(5)
+    run.sample(text, num_frames=c.segment_length, guidance_scale=7.5, generator=gen3, logits_log=log3, top_k=3)
+    raw3 = iter(run.out_tokens[:n_vis].cpu().tolist())
+    _, _, restricted, _ = forced_token_schedule(c, S, c.segment_length)
+    for step, i in enumerate(range(S + 1, full_len)):
+        if i in forced:
+            continue
+        tok = next(raw3)
+        if i not in restricted:
+            assert tok in torch.topk(log3[step][0], 3).indices.cpu().tolist(), (i, tok)
 
 
 def test_end_to_end_tiny(cuda, setup):
@@ -194,3 +206,29 @@ def test_end_to_end_tiny(cuda, setup):
     err = (video.cpu() - video32).abs().mean().item()
     assert err < max(2 * floor_v, 5e-3), (err, floor_v)
     assert frames.shape == frames_ref.shape and frames.dtype == torch.uint8
+
+
+@pytest.mark.parametrize("V,top_k,top_p", [(2055, 50, None), (2055, None, 0.9), (2055, 20, 0.5), (2055, None, 0.0),
+                                           (2055, 1, None), (37, 5, 0.7), (4096, 4000, 0.999)])
+def test_sampling_filters_top_k_top_p(cuda, V, top_k, top_p):
+    """a9: top-k on the tempered CFG logits then top_p_probability, against the oracle's restatement
+    (lm_model.py:441-447, utils.py:345-359).  The kept set is exact; values differ by summation order only."""
+    import torch.nn.functional as F
+    from landiff_amd import ops
+    from oracle.llm import top_p_probability
+    g = torch.Generator().manual_seed(V + (top_k or 0))
+    logits = torch.randn(2, V, generator=g) * 3
+    logits[0, 5] = logits[0, 9]                       # a tie inside the vocabulary
+    scale, temp = 7.5, 0.8
+    l = (logits[1] + scale * (logits[0] - logits[1]))[None] / temp
+    if top_k is not None:
+        v, _ = torch.topk(l, top_k)
+        l = l.masked_fill(l < v[:, [-1]], -float("inf"))
+    ref = F.softmax(l, dim=-1)
+    if top_p is not None:
+        ref = top_p_probability(top_p, ref)
+    probs = torch.empty(1, V, device=cuda)
+    ops.llm_logits_to_probs(logits.to(cuda), probs, None, True, scale, temp, top_k=top_k, top_p=top_p)
+    out = probs.cpu()
+    assert torch.equal(out > 0, ref > 0), ((out > 0).sum().item(), (ref > 0).sum().item())
+    assert (out - ref).abs().max().item() < 2e-6 and abs(out.sum().item() - 1) < 1e-5
