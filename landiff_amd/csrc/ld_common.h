@@ -49,11 +49,14 @@ __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w <<
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // ---- activations (fp32 math, matching torch's CPU/CUDA formulas) ----
+// 0.5*x*(1+tanh(u)) == x / (1 + exp(-2u)): one v_exp_f32 + one v_rcp_f32 instead of the tanhf call (the epilogue of the
+// 4h GEMM is VALU-bound otherwise); agrees with the tanh form to a few fp32 ulps, far inside the bf16 output rounding.
 __device__ __forceinline__ float act_gelu_tanh(float x) {
   const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
   const float kKappa = 0.044715f;
-  float inner = kBeta * (x + kKappa * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(inner));
+  const float u = kBeta * (x + kKappa * x * x * x);
+  const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * u);   // exp(-2u)
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float act_gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));

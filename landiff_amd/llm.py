@@ -207,7 +207,8 @@ class LLMRunner:
         c, dev = self.cfg, self.dev
         self.top_k, self.top_p = top_k, top_p
         guided = guidance_scale > 0 and guidance_scale != 1
-        assert guided, "the shipped pipeline always runs with CFG (cfg=7.5); unguided decode is not implemented"
+        # unguided (ARSampleCfg's dataclass default cfg=0.0, lm_model.py:311-319): the conditional row is independent of the
+        # second row, so the resident two-row buffers are kept and the sampling kernel reads row 0 only.
         feats = self.prefix_features(text_emb, float(num_frames), motion_score)
         S = feats.shape[1] - 1
         full_len, forced, restricted, n_visual = forced_token_schedule(c, S, num_frames)

@@ -160,6 +160,14 @@ def test_llm_teacher_forced_logits_and_sampler(cuda, setup):
     # 3) sampler exactness: given the device's own probabilities the same stream yields the same ids.
     agree = (ref_codes.reshape(-1) == codes.cpu()).float().mean().item()
     assert agree >= 0.8, agree
+    # unguided decode (cfg=0, the dataclass default): first-step logits equal the oracle's batch-1 prefill
+    logu = []
+    genu = torch.Generator(device=cuda); genu.manual_seed(2)
+    run.sample(text, num_frames=c.segment_length, guidance_scale=0.0, generator=genu, logits_log=logu)
+    _, ref_u = orc.sample(text, num_frames=c.segment_length, guidance_scale=0.0, return_logits=True,
+                          multinomial_fn=lambda p: torch.multinomial(p, 1))
+    erru = (logu[0].cpu() - ref_u[:1]).abs().max().item()
+    assert erru < 0.1 * max(1.0, ref_u[:1].abs().max().item()), erru
     # 4) top-k inside the decode loop (a9): every freely sampled token is one of the 3 best CFG logits of its step
     log3 = []
     gen3 = torch.Generator(device=cuda); gen3.manual_seed(5)
