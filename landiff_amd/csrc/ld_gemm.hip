@@ -145,8 +145,148 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, float (&v)[
   }
 }
 
+// Epilogue shared by both main loops: per MFMA row-block, accumulators -> wave-private LDS (fp32) -> row-contiguous
+// 16-byte stores (wave tile = MI x NI MFMA 32x32 tiles, NI * 32 == 64 columns).  Must be entered with all main-loop
+// LDS traffic of the whole workgroup retired (a barrier); inside, every wave works on its own staging tile, so the only
+// ordering needed is the in-order execution of one wave's own DS instructions -- no workgroup barriers.
+//
+// Code size is the constraint here: the epilogue is straight-line code that every wave walks once per tile, and a
+// body that carries every runtime feature (four activations inlined per element) grew the kernel past 160 KB -- more
+// than the instruction cache, so each tile paid tens of microseconds of instruction fetch.  The three epilogues of
+// the DiT layer are therefore compile-time specialisations (a few KB each, fully unrolled, operands of a row-block
+// requested before its accumulators are staged); everything else takes the compact generic path.
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE = 2, EPI_GENERIC = 3 };
+
+template <int MI, int NI, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], char* smem, int wave, int lane,
+                                              int row0, int col0w) {
+  float* cw = (float*)smem + wave * (32 * CW_STRIDE);
+  const int col0 = (lane & 7) * 8;
+  const int gn0 = col0w + col0;
+  auto stage_block = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        cw[row * CW_STRIDE + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+  };
+  if constexpr (EPI == EPI_GENERIC) {
+    const bool vec_ok = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) &&
+                        (p.resid == nullptr || (p.ldr & 7) == 0) &&
+                        (p.mul == nullptr || (p.ldmul & 7) == 0) &&
+                        (p.add2 == nullptr || (p.ldadd & 7) == 0);
+    auto row_block = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      stage_block(ic);
+#pragma unroll 1
+      for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 8 + (lane >> 3);
+        const int gm = row0 + i * 32 + row;
+        if (gm < p.M && gn0 < p.N) {
+          float v[8];
+          const f32x4_t lo = *(const f32x4_t*)(cw + row * CW_STRIDE + col0);
+          const f32x4_t hi = *(const f32x4_t*)(cw + row * CW_STRIDE + col0 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+          epilogue_store8(p, v, gm, gn0, vec_ok);
+        }
+      }
+    };
+    row_block(std::integral_constant<int, 0>{});
+    if constexpr (MI > 1) row_block(std::integral_constant<int, 1>{});
+    if constexpr (MI > 2) row_block(std::integral_constant<int, 2>{});
+    if constexpr (MI > 3) row_block(std::integral_constant<int, 3>{});
+  } else {
+    // specialised: N % 8 == 0, all leading dimensions % 8 == 0, bf16 output (checked by the launcher)
+    const bool col_ok = gn0 < p.N;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (p.bias && col_ok) {
+      const u32x4_t bw = *(const u32x4_t*)(p.bias + gn0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias[2 * e] = bf_lo(bw[e]); bias[2 * e + 1] = bf_hi(bw[e]); }
+    }
+    // gate row selection without a division per row: the tile's first batch and the next batch boundary
+    int bnd = 0, b0 = 0;
+    if constexpr (EPI == EPI_GATE) {
+      b0 = row0 / p.rows_per_batch;
+      bnd = (b0 + 1) * p.rows_per_batch;
+    }
+    const int rsub = lane >> 3;
+    auto row_block = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      u32x4_t g[4], rs[4], ad[4];
+      if constexpr (EPI == EPI_GATE) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int gm = row0 + i * 32 + ps * 8 + rsub;
+          g[ps] = rs[ps] = ad[ps] = (u32x4_t){0u, 0u, 0u, 0u};
+          if (gm < p.M && col_ok) {
+            const int b = gm >= bnd ? b0 + 1 : b0;
+            const int rin = gm - b * p.rows_per_batch;
+            g[ps] = *(const u32x4_t*)(p.gate + b * p.gate_bstride + (rin < p.text_len ? p.gate_off_txt : p.gate_off_img) + gn0);
+            rs[ps] = *(const u32x4_t*)((const bf16_t*)p.resid + (long)gm * p.ldr + gn0);
+            if (p.add2) ad[ps] = *(const u32x4_t*)(p.add2 + (long)gm * p.ldadd + gn0);
+          }
+        }
+      }
+      stage_block(ic);
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 8 + rsub;
+        const int gm = row0 + i * 32 + row;
+        const f32x4_t lo = *(const f32x4_t*)(cw + row * CW_STRIDE + col0);
+        const f32x4_t hi = *(const f32x4_t*)(cw + row * CW_STRIDE + col0 + 4);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = rbf(v[e] + bias[e]);                  // bf16 Linear output
+          if constexpr (EPI == EPI_GELU) x = act_gelu_tanh(x);
+          if constexpr (EPI == EPI_GATE) {
+            x = rbf(x * ((e & 1) ? bf_hi(g[ps][e >> 1]) : bf_lo(g[ps][e >> 1])));
+            x = rbf(((e & 1) ? bf_hi(rs[ps][e >> 1]) : bf_lo(rs[ps][e >> 1])) + x);
+            if (p.add2) x = rbf(x + ((e & 1) ? bf_hi(ad[ps][e >> 1]) : bf_lo(ad[ps][e >> 1])));   // pack below rounds again: idempotent
+          }
+          v[e] = x;
+        }
+        if (gm < p.M && col_ok) {
+          u32x4_t ow;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ow[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+          *(u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0) = ow;
+        }
+      }
+    };
+    // explicit expansion: a `#pragma unroll` over a body this large is silently dropped and acc[] lands in scratch
+    row_block(std::integral_constant<int, 0>{});
+    if constexpr (MI > 1) row_block(std::integral_constant<int, 1>{});
+    if constexpr (MI > 2) row_block(std::integral_constant<int, 2>{});
+    if constexpr (MI > 3) row_block(std::integral_constant<int, 3>{});
+  }
+  static_assert(MI <= 4, "extend the expansion");
+}
+
+// which specialisation a problem may use (the generic path handles everything)
+inline int pick_epilogue(const GemmParams& p) {
+  const bool aligned = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) && !p.out_f32 && !p.mul;
+  if (!aligned) return EPI_GENERIC;
+  if (p.gate && p.resid && !p.resid_f32 && p.act == 0 && (p.ldr & 7) == 0 && (!p.add2 || (p.ldadd & 7) == 0) &&
+      p.rows_per_batch >= 512)
+    return EPI_GATE;
+  if (p.gate || p.resid || p.add2) return EPI_GENERIC;
+  if (p.act == LD_ACT_GELU_TANH) return EPI_GELU;
+  if (p.act == 0) return EPI_BIAS;
+  return EPI_GENERIC;
+}
+
 // Block tile BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN) = MI x NI MFMA 32x32 tiles.
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
@@ -314,63 +454,264 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   }
   __syncthreads();
 
-  // ---- epilogue: per MFMA row-block, accumulators -> wave-private LDS (fp32) -> row-contiguous 16-B stores ----
-  float* cw = (float*)smem + wave * (32 * CW_STRIDE);
-  const bool vec_ok = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) &&
-                      (p.resid == nullptr || (p.ldr & 7) == 0) &&
-                      (p.mul == nullptr || (p.ldmul & 7) == 0) &&
-                      (p.add2 == nullptr || (p.ldadd & 7) == 0);
+  gemm_epilogue<MI, NI, EPI>(p, acc, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong main loop for the large DiT / TiTok GEMMs: 256x256 tile, 8 wave64 (2 along M x 4 along N, 128x64 per
+// wave = 4x2 MFMA 32x32x16 accumulators), two waves per SIMD that alternate roles every barrier interval:
+//
+//      wave group 0 (wr = 0):  B [load p] B [mfma p] B [load p+1] B [mfma p+1] ...
+//      wave group 1 (wr = 1):  B    B     [load p] B [mfma p]   B [load p+1] ...        (one barrier late)
+//
+// so that on every SIMD one wave owns the matrix pipe (8 MFMAs = one 16-deep k-step of its whole 128x64 tile) while
+// its partner issues the 6 ds_read_b128 of its next k-step and 2 LDS-DMA pieces of the prefetch stream.
+//   * K is consumed in 32-deep tiles (two phases each); LDS holds a ring of four 32 KB tiles (A 256x32 | W 256x32,
+//     64-byte rows, 16-byte chunk index XOR ((row >> 2) & 3) on the DMA source and on the read = conflict-free
+//     ds_read_b128).  The ring is fed in 16 KB units (unit u = A part (even) / W part (odd) of tile u/2), one unit per
+//     phase, unit u issued in phase u - 5.
+//   * RAW: the odd phase of tile t ends with a counted s_waitcnt vmcnt (3 units stay in flight) before its barrier; tile
+//     t + 1 is first read one barrier later (two for the late group).  WAR: unit u overwrites tile u/2 - 4, whose last
+//     ds_reads were retired (lgkmcnt(0) ahead of the MFMAs) by both groups at least one barrier before phase u - 5.
+//   * Raw s_barrier throughout: __syncthreads() would drain the LDS-DMA queue (vmcnt(0)) at every barrier.
+template <bool CONV, int EPI, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void ld_gemm_pp_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, KT = 32;
+  constexpr int A_BYTES = BM * KT * 2;              // 16 KB
+  constexpr int SLOT = (BM + BN) * KT * 2;          // 32 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, nbm * nbn);
+  const int gm_sz = p.group_m;
+  const int per_group = gm_sz * nbn;
+  const int group = bid / per_group, in_group = bid - group * per_group;
+  const int first_m = group * gm_sz;
+  const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+  const int m0 = (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
+
+  // LDS-DMA sources: a 1 KB piece = 16 rows x 64 B; every wave brings 2 pieces of each 16 KB unit
+  const bf16_t* srcA[2];
+  const bf16_t* srcW[2];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        cw[row * CW_STRIDE + j * 32 + (lane & 31)] = acc[i][j][r];
-      }
-    __syncthreads();
-#pragma unroll 1
-    for (int ps = 0; ps < 4; ++ps) {
-      const int row = ps * 8 + (lane >> 3);
-      const int col0 = (lane & 7) * 8;
-      const int gm = m0 + wr * (BM / WM) + i * 32 + row;
-      const int gn0 = n0 + wc * 64 + col0;
-      if (gm < p.M && gn0 < p.N) {
-        float v[8];
-        const f32x4_t lo = *(const f32x4_t*)(cw + row * CW_STRIDE + col0);
-        const f32x4_t hi = *(const f32x4_t*)(cw + row * CW_STRIDE + col0 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-        epilogue_store8(p, v, gm, gn0, vec_ok);
-      }
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+    int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+    if (CONV) {
+      const int hw = p.H * p.W_;
+      const int t = gm / hw, rem = gm - t * hw;
+      const int h = rem / p.W_, w = rem - h * p.W_;
+      srcA[i] = p.A + (((long)t * p.Hp + h) * p.Wp + w) * p.Cin + chunk * 8;
+    } else {
+      srcA[i] = p.A + (long)gm * p.lda + chunk * 8;
     }
-    __syncthreads();
+    srcW[i] = p.W + (long)gn * p.K + chunk * 8;
   }
+  const int nk = p.K / KT;            // K tiles (multiple of 4, checked by the launcher)
+  const int nunits = 2 * nk;
+  const int cpt = CONV ? p.Cin / KT : 1;
+  auto stage = [&](int slot, int u) {               // slot: compile-time at every call site
+    const int t = u >> 1;
+    char* base = smem + slot * SLOT + wave * 2048;
+    if ((u & 1) == 0) {
+      long koff;
+      if (CONV) {
+        const int tap = t / cpt, c0 = (t - tap * cpt) * KT;
+        const int khw = p.kH * p.kW;
+        const int dt = tap / khw, r2 = tap - dt * khw;
+        const int dh = r2 / p.kW, dw = r2 - dh * p.kW;
+        koff = (((long)dt * p.Hp + dh) * p.Wp + dw) * p.Cin + c0;
+      } else {
+        koff = (long)t * KT;
+      }
+      glds16(srcA[0] + koff, base);
+      glds16(srcA[1] + koff, base + 1024);
+    } else {
+      const long koff = (long)t * KT;
+      glds16(srcW[0] + koff, base + A_BYTES);
+      glds16(srcW[1] + koff, base + A_BYTES + 1024);
+    }
+  };
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets inside a slot for the two k-steps of a tile (+2048 B per further 32-row MFMA tile)
+  int rdA[2], rdB[2];
+  {
+    const int ra = wr * 128 + (lane & 31), rb = wc * 64 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = kk * 2 + (lane >> 5);
+      rdA[kk] = ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
+      rdB[kk] = A_BYTES + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
+    }
+  }
+
+  unsigned long long tL = 0, tB1 = 0, tM = 0, tB2 = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#define STAMP(x) do { if (DBG & 64) asm volatile("s_memtime %0" : "=s"(x)); } while (0)
+  auto phase = [&](auto slotc, auto kkc, int t) {
+    constexpr int S = decltype(slotc)::value, KK = decltype(kkc)::value;
+    // ---- load segment (partner wave is in its MFMA segment) ----
+    if (DBG & 64) {                   // previous phase's stamps are all retired here
+      unsigned long long s0n;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s0n));
+      if (s3) { tL += s1 - s0; tB1 += s2 - s1; tM += s3 - s2; tB2 += s0n - s3; }
+      s0 = s0n;
+    }
+    bf16x8_t a[4], b[2];
+    if (DBG & 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(a[i]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(b[j]));
+    } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8_t*)(smem + rdA[KK] + S * SLOT + i * 2048);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8_t*)(smem + rdB[KK] + S * SLOT + j * 2048);
+    }
+    if (!(DBG & 1)) {
+      const int u = 2 * t + KK + 5;
+      if (u < nunits) stage(KK == 0 ? (S + 2) & 3 : (S + 3) & 3, u);
+    }
+    if (KK == 1) {
+      if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    STAMP(s1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(s2);
+    // ---- MFMA segment ----
+    if (!(DBG & 16)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    if (!(DBG & 16)) __builtin_amdgcn_s_setprio(0);
+    STAMP(s3);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: units 0..4 (tiles 0, 1 and the A part of tile 2), tile 0 complete, stagger the late group ----
+  stage(0, 0); stage(0, 1); stage(1, 2); stage(1, 3); stage(2, 4);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1 && !(DBG & 4)) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int t = 0; t < nk; t += 4) {
+    phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t);
+    phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t);
+    phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t + 1);
+    phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1);
+    phase(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, t + 2);
+    phase(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, t + 2);
+    phase(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, t + 3);
+    phase(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, t + 3);
+  }
+  if (wr == 0 && !(DBG & 4)) __builtin_amdgcn_s_barrier();     // the early group waits for the late group's last MFMA segment
+  __syncthreads();
+  if (DBG & 64) {
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    if (bid == 0 && lane == 0) {
+      unsigned long long* d = (unsigned long long*)p.out + wave * 4;
+      d[0] = tL; d[1] = tB1; d[2] = tM; d[3] = tB2;
+    }
+  }
+  if (DBG & 8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+    return;
+  }
+  gemm_epilogue<4, 2, EPI>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64);
+}
+
+
+template <auto Kernel>
+int launch_kernel(const char* what, dim3 grid, dim3 block, int smem, hipStream_t stream, const GemmParams& p) {
+  static bool attr_set = false;      // per kernel instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(Kernel, grid, block, smem, stream, p);
+  return ld_check_launch(what);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
   constexpr int NW = WM * WN;
   constexpr int STAGE = (BM + BN) * BK * 2;
-  constexpr int EPI = NW * 32 * CW_STRIDE * 4;
-  constexpr int SMEM = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
+  constexpr int EPIB = NW * 32 * CW_STRIDE * 4;
+  constexpr int SMEM = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   dim3 grid(nbm * nbn), block(NW * 64);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    (void)hipFuncSetAttribute((const void*)ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
+  const int epi = pick_epilogue(p);
+#define LD_GEMM_LAUNCH(CONV_, EPI_) \
+  return launch_kernel<ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, CONV_, EPI_>>("ld_gemm", grid, block, SMEM, stream, p)
+  if (conv) {
+    if (epi == EPI_BIAS) LD_GEMM_LAUNCH(true, EPI_BIAS);
+    LD_GEMM_LAUNCH(true, EPI_GENERIC);
   }
-  if (conv) hipLaunchKernelGGL((ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, block, SMEM, stream, p);
-  else hipLaunchKernelGGL((ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, block, SMEM, stream, p);
-  return ld_check_launch("ld_gemm");
+  switch (epi) {
+    case EPI_BIAS: LD_GEMM_LAUNCH(false, EPI_BIAS);
+    case EPI_GELU: LD_GEMM_LAUNCH(false, EPI_GELU);
+    case EPI_GATE: LD_GEMM_LAUNCH(false, EPI_GATE);
+    default: LD_GEMM_LAUNCH(false, EPI_GENERIC);
+  }
+#undef LD_GEMM_LAUNCH
+}
+
+int launch_pp(const GemmParams& p, bool conv, hipStream_t stream) {
+  constexpr int SMEM = 4 * (256 + 256) * 32 * 2;   // 128 KB ring (the epilogue staging reuses it)
+  const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
+  dim3 grid(nbm * nbn), block(512);
+  const int epi = pick_epilogue(p);
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("LD_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+#define PP_DBG_CASE(D) case D: return launch_kernel<ld_gemm_pp_kernel<false, EPI_BIAS, D>>("ld_gemm_pp_dbg", grid, block, SMEM, stream, p);
+  if (dbg && !conv && epi == EPI_BIAS) switch (dbg) {
+    PP_DBG_CASE(1) PP_DBG_CASE(2) PP_DBG_CASE(3) PP_DBG_CASE(4) PP_DBG_CASE(8) PP_DBG_CASE(11) PP_DBG_CASE(16) PP_DBG_CASE(72) PP_DBG_CASE(73) PP_DBG_CASE(74) PP_DBG_CASE(75)
+    default: break;
+  }
+#undef PP_DBG_CASE
+#define LD_PP_LAUNCH(CONV_, EPI_) return launch_kernel<ld_gemm_pp_kernel<CONV_, EPI_>>("ld_gemm_pp", grid, block, SMEM, stream, p)
+  if (conv) {
+    if (epi == EPI_BIAS) LD_PP_LAUNCH(true, EPI_BIAS);
+    LD_PP_LAUNCH(true, EPI_GENERIC);
+  }
+  switch (epi) {
+    case EPI_BIAS: LD_PP_LAUNCH(false, EPI_BIAS);
+    case EPI_GELU: LD_PP_LAUNCH(false, EPI_GELU);
+    case EPI_GATE: LD_PP_LAUNCH(false, EPI_GATE);
+    default: LD_PP_LAUNCH(false, EPI_GENERIC);
+  }
+#undef LD_PP_LAUNCH
 }
 
 int launch(const GemmParams& p, bool conv, hipStream_t stream) {
-  // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves / 2 stages, 2 = 256x128 / 8 waves / 2 stages,
-  // 5 = 256x128 / 8 waves / 3-stage counted-vmcnt ring, 6 = 128x128 / 4 waves / 3-stage ring
+  // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves, 3 = 256x256 / 8 waves (both 2-stage, barrier-drained),
+  // 7 = 256x256 / 8 waves ping-pong main loop
   static int forced = -1, group_m = 8;
   if (forced < 0) {
     const char* e = getenv("LD_GEMM_TILE"); forced = e ? atoi(e) : 0;
@@ -384,13 +725,10 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     cfg = (tiles256 >= 512 && (p.N >= 4096 || p.K >= 4096)) ? 3 : 1;
   }
-  switch (cfg) {
-    case 6: return launch_cfg<128, 128, 2, 2, 3>(p, conv, stream);
-    case 3: return launch_cfg<256, 256, 2, 4, 2>(p, conv, stream);
-    case 5: return launch_cfg<256, 128, 4, 2, 3>(p, conv, stream);
-    case 2: return launch_cfg<256, 128, 4, 2, 2>(p, conv, stream);
-    default: return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
-  }
+  const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
+  if (cfg == 7 && pp_ok) return launch_pp(p, conv, stream);
+  if (cfg == 3 || cfg == 7) return launch_cfg<256, 256, 2, 4, 2>(p, conv, stream);
+  return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
 }
 
 int fill_epilogue(GemmParams& p, const ld_epilogue_t* e) {
