@@ -24,60 +24,9 @@
 //     source address and on the read: conflict-free ds_read_b128.
 //   * frame-block mask: per-KV-tile [min,max] frame ids let a workgroup skip fully masked
 //     tiles (no load, no MFMA) and apply the element mask only on the few straddling tiles.
-#include "ld_common.h"
-#include "../../include/landiff_hip.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "ld_attn.h"
 
 namespace {
-
-constexpr int QB = 128;   // query rows per workgroup
-constexpr int KT = 64;    // keys per tile
-constexpr int D = 64;
-constexpr int KTILE_BYTES = KT * D * 2;       // 8 KB
-constexpr int STAGE_BYTES = 2 * KTILE_BYTES;  // K + V^T
-constexpr float NEG_BIG = -1.0e30f;
-
-struct AttnParams {
-  const bf16_t* Q;    // [BH][Npad][64]
-  const bf16_t* K;    // [BH][Npad][64]
-  const bf16_t* Vt;   // [BH][64][Npad]
-  bf16_t* O;          // [B][Nq][H*64] (row stride o_rs, batch stride o_bs)
-  int B, H, Nq, Nk, Npad;
-  long o_bs, o_rs;
-  float c;            // softmax_scale * log2(e)
-  const int* fid_q;   // [Npad] or null
-  const int* fid_k;   // [Npad] or null (padding keys must carry INT_MAX)
-  const int* kt_min;  // [Npad/64]
-  const int* kt_max;
-};
-
-__device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(
-      (const __attribute__((address_space(1))) void*)g,
-      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-__device__ __forceinline__ float lane32_max(float x) {
-  // max(x, value of lane^32)
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float lane32_sum(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// v_max3_f32 by hand: plain fmaxf on MFMA outputs makes hipcc insert a canonicalising v_max per operand
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
-__device__ __forceinline__ int swap23(int i) {
-  return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
-}
 
 // LAZY: no max pre-pass.  P = exp2(S' - m_old) is formed directly, packed to bf16 and summed with v_dot2c_f32_bf16; only
 // when a lane's partial sum shows that some score outgrew the running max by more than ~2^8 (or on the first valid tile)
@@ -689,6 +638,8 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe_kernel(AttnParams p) {
 
 }  // namespace
 
+int ld_attn_pipe2_launch(const AttnParams& p, dim3 grid, hipStream_t st);   // ld_attn_pipe.hip
+
 LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
                             int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
                             int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
@@ -710,12 +661,17 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   dim3 grid((unsigned)(B * H * nqb)), block(256);
   static int var = -1;
   if (var < 0) {
-    const char* e = getenv("LD_ATTN_VARIANT");     // tuning knob: 0 = VALU row sums, 1 = row sums on the matrix pipe
+    // tuning knob: 0 = default (pipelined kernel of ld_attn_pipe.hip where it applies, else the plain kernel),
+    // 9 = plain kernel everywhere, 1/4/5/6/7 = experimental forms of the plain kernel
+    const char* e = getenv("LD_ATTN_VARIANT");
     var = e ? atoi(e) : 0;
   }
   hipStream_t st = (hipStream_t)stream;
   const size_t s1 = 2 * STAGE_BYTES + 64;
-  if (var == 5 && !fid_k) hipLaunchKernelGGL((ld_attn_pipe_kernel<0>), grid, block, 4 * KTILE_BYTES, st, p);
+  const int64_t nkt = (Nk + KT - 1) / KT;
+  if ((var == 0 || var == 8) && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {
+    return ld_attn_pipe2_launch(p, grid, st);
+  } else if (var == 5 && !fid_k) hipLaunchKernelGGL((ld_attn_pipe_kernel<0>), grid, block, 4 * KTILE_BYTES, st, p);
   else if (var == 6) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 3, true>), grid, block, s1, st, p);
   else if (var == 7) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 2, true>), grid, block, s1, st, p);
   else if (var == 1) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);
