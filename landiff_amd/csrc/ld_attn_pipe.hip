@@ -28,9 +28,12 @@
 //     pipeline with the running maximum, the deferred rescale and VALU row sums.
 //
 // LDS: four K slots and four V^T slots of 8 KB (tile t in slot t & 3; 64 KB per workgroup, 2 workgroups per CU).
-// RAW: a wave waits for its own LDS-DMA pieces two iterations back (vmcnt(8)) before the barrier that precedes the
-// first read.  WAR: a slot is refilled one barrier after the last ds_read of it was retired (lgkmcnt(0) before every
-// barrier).
+// Iterations come in pairs ("periods") with ONE workgroup barrier per pair: period m = iterations 2m, 2m+1 reads V_2m,
+// V_2m+1, K_2m+2, K_2m+3 and, in its first iteration, issues the LDS-DMA of V_2m+2, V_2m+3, K_2m+4, K_2m+5 into the four
+// slots that period m-1 finished reading.  RAW: every wave drains its own DMA pieces (vmcnt(0)) before the barrier that
+// ends the period; the next period reads them.  WAR: lgkmcnt(0) before the same barrier retires the period's ds_reads
+// before any wave refills those slots.  The DMA itself is buffer_load ... lds with the tile offset in an SGPR (soffset)
+// and a loop-invariant per-lane voffset: no VALU address arithmetic in the loop.
 #include "ld_attn.h"
 
 namespace {
@@ -69,10 +72,11 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
     }
   }
 
-  // LDS-DMA: waves 0,1 bring K tiles (rows = keys), waves 2,3 bring V^T tiles (rows = d); 4 x 1 KB pieces per wave
+  // LDS-DMA: waves 0,1 bring K tiles (rows = keys), waves 2,3 bring V^T tiles (rows = d); 4 x 1 KB pieces per wave and tile
   const bool kwave = wave < 2;
-  const char* src_base = (const char*)(kwave ? Kb : Vb);          // wave-uniform
-  const long tstride = kwave ? (long)KT * D * 2 : (long)KT * 2;   // bytes per tile step in the source
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(kwave ? Kb : Vb), 0, 0x7fffffff, 0x00020000);   // raw buffer, wave-uniform
+  const int tstride = kwave ? KT * D * 2 : KT * 2;               // bytes per tile step in the source
   const int rstride = kwave ? D : p.Npad;
   uint32_t goff[4];
   int ldsoff[4];
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
     ldsoff[i] = (kwave ? 0 : VBASE) + piece * 1024;
   }
   auto dma_piece = [&](int i, int slot, int t) {
-    const char* tb = src_base + t * tstride;
-    glds16((const bf16_t*)(tb + goff[i]), smem + slot * KTILE_BYTES + ldsoff[i]);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + slot * KTILE_BYTES + ldsoff[i]),
+                                             16, goff[i], t * tstride, 0, 0);
   };
   auto dma = [&](int slot, int t) {
 #pragma unroll
@@ -164,17 +168,18 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
     };
 
     // One pipelined iteration.  sc = S_j, sn receives S_{j+1}.  HAS_QK: tile j+1 exists; HAS_K2: tile j+2 exists (a main-loop
-    // iteration); MASK: tile j+1 is the ragged one.  Main-loop iterations always issue their four DMA pieces (straight-line
-    // code, uniform vmcnt accounting); past the end the tile index is clamped, which re-fetches tile n-1 into a slot nobody
-    // reads.  The two final iterations issue none.
+    // iteration); MASK: tile j+1 is the ragged one.  Even main-loop iterations issue the period's eight DMA pieces (past the
+    // end the tile index is clamped, which re-fetches tile n-1 into a slot nobody reads); odd iterations end the period.
     auto iter = [&](f32x16_t (&sc)[2], f32x16_t (&sn)[2], int j, auto vslot_c, auto has_qk_c, auto has_k2_c, auto mask_c) {
       constexpr int vslot = decltype(vslot_c)::value;            // slot of V_j; the others follow from it
-      constexpr int k2slot = (vslot + 2) & 3, kdslot = (vslot + 1) & 3, vdslot = (vslot + 3) & 3;
+      constexpr int k2slot = (vslot + 2) & 3;
       constexpr bool HAS_QK = decltype(has_qk_c)::value, HAS_K2 = decltype(has_k2_c)::value, MASK = decltype(mask_c)::value;
-      constexpr bool do_dma = HAS_K2;
-      const int dslot = kwave ? kdslot : vdslot;
-      int dt = kwave ? j + 5 : j + 3;
-      dt = dt < n ? dt : n - 1;
+      constexpr bool EVEN = (vslot & 1) == 0;
+      constexpr bool do_dma = HAS_K2 && EVEN;
+      // even iteration j = 2m: V_j+2, V_j+3 go to V slots (j + 2) & 3, (j + 3) & 3; K_j+4, K_j+5 to K slots j & 3, (j + 1) & 3
+      int dt0 = kwave ? j + 4 : j + 2, dt1 = dt0 + 1;
+      dt0 = dt0 < n ? dt0 : n - 1; dt1 = dt1 < n ? dt1 : n - 1;
+      const int dslot0 = kwave ? vslot : (vslot + 2) & 3, dslot1 = kwave ? (vslot + 1) & 3 : (vslot + 3) & 3;
       u32x4_t pw[4];
       float m0 = NEG_BIG, m1 = NEG_BIG;
       auto EXP2 = [&](int i, int r) {        // two scores -> probabilities (SAFE: + row sums)
@@ -204,14 +209,14 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
         if (FAST && MSUM) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8_t, pw[ks]), acc0, 0, 0, 0);
       };
       // ---- QK^T of tile j+1 over exp2 of the first 32 keys of tile j ----
-      QK(0); EXP2(0, 0);  VF(0); if (do_dma) dma_piece(0, dslot, dt); FENCE();
-      QK(1); EXP2(0, 2);  VF(1); if (do_dma) dma_piece(1, dslot, dt); FENCE();
-      QK(2); EXP2(0, 4);  VF(2); if (do_dma) dma_piece(2, dslot, dt); FENCE();
-      QK(3); EXP2(0, 6);  VF(3); if (do_dma) dma_piece(3, dslot, dt); FENCE();
-      QK(4); EXP2(0, 8);  VF(4); FENCE();
-      QK(5); EXP2(0, 10); VF(5); FENCE();
-      QK(6); EXP2(0, 12); VF(6); CVT2(0, 0); FENCE();
-      QK(7); EXP2(0, 14); VF(7); CVT2(0, 2); FENCE();
+      QK(0); EXP2(0, 0);  VF(0); if (do_dma) dma_piece(0, dslot0, dt0); FENCE();
+      QK(1); EXP2(0, 2);  VF(1); if (do_dma) dma_piece(1, dslot0, dt0); FENCE();
+      QK(2); EXP2(0, 4);  VF(2); if (do_dma) dma_piece(2, dslot0, dt0); FENCE();
+      QK(3); EXP2(0, 6);  VF(3); if (do_dma) dma_piece(3, dslot0, dt0); FENCE();
+      QK(4); EXP2(0, 8);  VF(4); if (do_dma) dma_piece(0, dslot1, dt1); FENCE();
+      QK(5); EXP2(0, 10); VF(5); if (do_dma) dma_piece(1, dslot1, dt1); FENCE();
+      QK(6); EXP2(0, 12); VF(6); CVT2(0, 0); if (do_dma) dma_piece(2, dslot1, dt1); FENCE();
+      QK(7); EXP2(0, 14); VF(7); CVT2(0, 2); if (do_dma) dma_piece(3, dslot1, dt1); FENCE();
       if (MASK) mask_tail(sn, j + 1);
       if (FAST && MSUM) {
         // ---- PV + row sums (12 MFMAs) over exp2 of the last 32 keys ----
@@ -239,18 +244,19 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
         PV(7); KF(7); MAX4(m1, 1, 12); FENCE();
         if (HAS_QK) rebase_if(sn, fmaxf(m0, m1), false);
       }
-      // ---- end of iteration: retire this wave's LDS reads and its two-iterations-old DMA pieces, then the barrier.
+      // ---- end of a period (odd iteration): retire this wave's LDS reads and DMA pieces, then the barrier.
       //      (the builtin, unlike inline asm, is visible to hipcc's own wait-count bookkeeping: no redundant waits follow)
-      if (do_dma) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0)
-      else __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
-      __builtin_amdgcn_s_barrier();
+      if (!EVEN) {
+        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+      }
       FENCE();
     };
 
-    // ---- prologue: K0..K3, V0..V2 in flight; S_0; K_1 fragments; K4 into K0's slot ----
+    // ---- prologue: K0..K3, V0, V1 land; S_0 from K0; K_1 fragments ----
     if (kwave) { dma(0, 0); dma(1, 1); dma(2, 2); dma(3, 3); }
-    else { dma(0, 0); dma(1, 1); dma(2, 2); }
-    if (kwave) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else { dma(0, 0); dma(1, 1); }
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     FENCE();
     load_kf(0);
@@ -259,15 +265,11 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         sA[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][kk], qf[kk], kk == 0 ? zero16 : sA[i], 0, 0, 0);
-    if (kwave) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     FENCE();
-    __builtin_amdgcn_s_barrier();        // every wave has K0 in registers (the MFMAs above consumed the ds_reads)
-    FENCE();
-    if (kwave) dma(0, 4);
     load_kf(1);
     if (!FAST) rebase_if(sA, tile_max(sA), true);
-    __builtin_amdgcn_s_waitcnt(0x0078);
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();        // every wave has K0 / K1 in registers: period 0 may refill their slots
     FENCE();
 
     // ---- main loop: iterations j = 0 .. n-3 (tiles j+1 and j+2 exist, tile j+1 is never the ragged one) ----

@@ -51,6 +51,7 @@ struct GemmParams {
   // conv (channels-last, zero-bordered input)
   int H, W_, Hp, Wp, Cin, kH, kW;   // output H,W; padded input Hp,Wp
   int group_m;                      // tile-raster group height (L2 locality)
+  int m_begin;                      // first output row of this launch (rows stay absolute: M is the end row)
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
@@ -305,14 +306,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   // Tile order: blockIdx -> XCD-contiguous logical id (each XCD has a private 4 MB L2) -> grouped raster: the ~64
   // tiles resident on one XCD form a GROUP_M x (64/GROUP_M) patch, so an A panel and a W panel are each re-read from
   // L2 ~8 times instead of W being re-streamed from MALL/HBM for every row of tiles.
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, nbm * nbn);
   const int gm_sz = p.group_m;
   const int per_group = gm_sz * nbn;
   const int group = bid / per_group, in_group = bid - group * per_group;
   const int first_m = group * gm_sz;
   const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
-  const int m0 = (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
+  const int m0 = p.m_begin + (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
 
   // ---- per-thread source row offsets ----
   uint32_t offA[A_LOADS], offW[B_LOADS];    // element offsets (< 2^31 for every shape on the path)
@@ -485,14 +486,14 @@ __global__ __launch_bounds__(512, 2) void ld_gemm_pp_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, nbm * nbn);
   const int gm_sz = p.group_m;
   const int per_group = gm_sz * nbn;
   const int group = bid / per_group, in_group = bid - group * per_group;
   const int first_m = group * gm_sz;
   const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
-  const int m0 = (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
+  const int m0 = p.m_begin + (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
 
   // LDS-DMA sources: a 1 KB piece = 16 rows x 64 B; every wave brings 2 pieces of each 16 KB unit
   const bf16_t* srcA[2];
@@ -664,7 +665,7 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int EPIB = NW * 32 * CW_STRIDE * 4;
   constexpr int SMEM = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   dim3 grid(nbm * nbn), block(NW * 64);
   const int epi = pick_epilogue(p);
 #define LD_GEMM_LAUNCH(CONV_, EPI_) \
@@ -684,7 +685,7 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
 
 int launch_pp(const GemmParams& p, bool conv, hipStream_t stream) {
   constexpr int SMEM = 4 * (256 + 256) * 32 * 2;   // 128 KB ring (the epilogue staging reuses it)
-  const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
+  const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
   dim3 grid(nbm * nbn), block(512);
   const int epi = pick_epilogue(p);
   static int dbg = -1;
@@ -726,9 +727,31 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     cfg = (tiles256 >= 512 && (p.N >= 4096 || p.K >= 4096)) ? 3 : 1;
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
-  if (cfg == 7 && pp_ok) return launch_pp(p, conv, stream);
-  if (cfg == 3 || cfg == 7) return launch_cfg<256, 256, 2, 4, 2>(p, conv, stream);
-  return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  if (cfg != 3 && cfg != 7) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  auto big = [&](const GemmParams& q) {
+    return (cfg == 7 && pp_ok) ? launch_pp(q, conv, stream) : launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);
+  };
+  // Wave quantisation: one 256x256 tile per CU at a time, so a grid of 4.3 "rounds" of 256 tiles costs 5.  When the last
+  // round would be less than ~60 % full, the bottom rows are cut off and run as 128x128 tiles (two per CU, four times as
+  // many) in a second launch: DiT proj / 4h->h GEMMs (N = 1920: 1112 tiles = 4.34 rounds) gain ~12 %.
+  static int split = -1;
+  if (split < 0) { const char* e = getenv("LD_GEMM_MSPLIT"); split = e ? atoi(e) : 1; }
+  const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
+  const long tiles = (long)nbm * nbn;
+  const int ncu = 256;
+  const long full = tiles / ncu, rem = tiles % ncu;
+  if (split && !conv && p.m_begin == 0 && full >= 2 && rem > 0 && rem * 100 <= 60 * ncu) {
+    const int rows_main = (int)((full * ncu) / nbn);           // whole tile rows that fit in `full` rounds
+    if (rows_main > 0 && rows_main < nbm) {
+      GemmParams a = p, b = p;
+      a.M = rows_main * 256;
+      b.m_begin = rows_main * 256;
+      const int rc = big(a);
+      if (rc) return rc;
+      return launch_cfg<128, 128, 2, 2, 2>(b, conv, stream);
+    }
+  }
+  return big(p);
 }
 
 int fill_epilogue(GemmParams& p, const ld_epilogue_t* e) {
