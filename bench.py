@@ -154,12 +154,12 @@ def main():
                        "sampler_steps": cfg.sampler.num_steps, "llm_steps": 1244 if not args.tiny else None,
                        "parallelism": f"dp{world} over prompts, RCCL all_gather of uint8 frames only"},
             "stage_seconds_rank0": {k: round(v / args.steps, 3) for k, v in pipe.timings.items()},
-            "roofline": {"kernel": "ld_attn_kernel (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (d.heads, d.seq_len),
+            "roofline": {"kernel": "ld_attn_pipe2_kernel (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (d.heads, d.seq_len),
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
-                         # HBM bytes per launch from rocprofv3 PMC passes at this shape (profiles/r01_attn_pmc_*.csv):
-                         # (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) x 1024 = (2*761509 + 183360) KiB
-                         "traffic": (2 * 761509 + 183360) * 1024 if not args.tiny else None, "launches": len(ev),
+                         # HBM bytes per launch from rocprofv3 PMC passes at this shape (profiles/r01c_attn_pipe2_pmc_hbm.csv):
+                         # (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) x 1024 = (2*751100 + 133300) KiB
+                         "traffic": (2 * 751100 + 133300) * 1024 if not args.tiny else None, "launches": len(ev),
                          "avg_launch_ms": round(attn_ms, 4)},
         }
         if not args.no_cpu_baseline and world == 1:
