@@ -648,6 +648,164 @@ __global__ __launch_bounds__(512, 2) void ld_gemm_pp_kernel(GemmParams p) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// One-wave-per-SIMD main loop: 256x256 tile, 4 wave64 as 2x2, each wave a 128x128 output = 4x4 MFMA 32x32x16
+// accumulators (256 registers; the kernel runs at one wave per SIMD, 512 registers per lane).  Compared with eight
+// 128x64 waves this reads a third less LDS per MFMA (8 ds_read_b128 per 16 MFMAs instead of 12) and needs no
+// load/compute role split: each wave software-pipelines itself -- the 8 fragment reads of k-step s+1 and this wave's
+// LDS-DMA pieces are issued between the 16 MFMAs of k-step s (order pinned with sched_barrier(0)), so the matrix pipe
+// sees back-to-back MFMAs on 16 independent accumulators.
+//   * K is consumed in 32-deep tiles; LDS holds a ring of four 32 KB tiles (A 256x32 | W 256x32, 64-byte rows, 16-byte
+//     chunk XOR ((row >> 2) & 3) on the DMA source and on the read).  The DMA is buffer_load ... lds with a loop-invariant
+//     per-lane voffset and the K offset in an SGPR: no VALU address arithmetic in the loop.
+//   * One barrier per K-tile, between its two k-steps.  Tile t's slot is last read during step (t,0) (fragments of
+//     (t,1)); after barrier B_t it is refilled with tile t+4.  RAW: before B_t every wave waits until only its pieces of
+//     tiles t+2, t+3 are outstanding (vmcnt(16)), so tile t+1 -- first read right after B_t -- is complete everywhere.
+template <bool CONV, int EPI>
+__global__ __launch_bounds__(256, 1) void ld_gemm_w4_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, KT = 32;
+  constexpr int A_BYTES = BM * KT * 2;              // 16 KB
+  constexpr int SLOT = (BM + BN) * KT * 2;          // 32 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, nbm * nbn);
+  const int gm_sz = p.group_m;
+  const int per_group = gm_sz * nbn;
+  const int group = bid / per_group, in_group = bid - group * per_group;
+  const int first_m = group * gm_sz;
+  const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+  const int m0 = p.m_begin + (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
+
+  // LDS-DMA: a 1 KB piece = 16 rows x 64 B; per K-tile every wave brings 4 pieces of A and 4 of W
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
+  uint32_t voA[4], voW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+    int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+    if (CONV) {
+      const int hw = p.H * p.W_;
+      const int t = gm / hw, rem = gm - t * hw;
+      const int h = rem / p.W_, w = rem - h * p.W_;
+      voA[i] = (uint32_t)(((((long)t * p.Hp + h) * p.Wp + w) * p.Cin + chunk * 8) * 2);
+    } else {
+      voA[i] = (uint32_t)(((long)gm * p.lda + chunk * 8) * 2);
+    }
+    voW[i] = (uint32_t)(((long)gn * p.K + chunk * 8) * 2);
+  }
+  const int nk = p.K / KT;
+  const int cpt = CONV ? p.Cin / KT : 1;
+  auto koff_a = [&](int t) -> int {                 // byte offset of K-tile t in an A row (wave-uniform)
+    if (CONV) {
+      const int tap = t / cpt, c0 = (t - tap * cpt) * KT;
+      const int khw = p.kH * p.kW;
+      const int dt = tap / khw, r2 = tap - dt * khw;
+      const int dh = r2 / p.kW, dw = r2 - dh * p.kW;
+      return (int)(((((long)dt * p.Hp + dh) * p.Wp + dw) * p.Cin + c0) * 2);
+    }
+    return t * KT * 2;
+  };
+  // piece q of a tile's 8 (0-3: A, 4-7: W) for this wave
+  auto dma_piece = [&](int q, int slot, int soffA, int soffW) {
+    char* base = smem + slot * SLOT + wave * 4096;
+    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, voA[q], soffA, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + A_BYTES + (q - 4) * 1024), 16, voW[q - 4], soffW, 0, 0);
+  };
+
+  f32x16_t acc[2][4][2];       // [column half][row block][column block in the half]: the epilogue takes one half at a time
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+  int rdA[2], rdB[2];          // fragment read offsets inside a slot for the two k-steps (+2048 B per further 32 rows)
+  {
+    const int ra = wr * 128 + (lane & 31), rb = wc * 128 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = kk * 2 + (lane >> 5);
+      rdA[kk] = ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
+      rdB[kk] = A_BYTES + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
+    }
+  }
+  bf16x8_t fa[2][4], fb[2][4];     // two fragment sets: the k-step being multiplied and the next one
+  auto FRAG = [&](auto bufc, int slot, int kk, int g) {       // g = 0..7: A row blocks 0-3, W column blocks 0-3
+    constexpr int B = decltype(bufc)::value;
+    if (g < 4) fa[B][g] = *(const bf16x8_t*)(smem + rdA[kk] + slot * SLOT + g * 2048);
+    else fb[B][g - 4] = *(const bf16x8_t*)(smem + rdB[kk] + slot * SLOT + (g - 4) * 2048);
+  };
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one k-step: 16 MFMAs on fragment set B; behind them the 8 fragment reads of the next k-step (set 1-B, slot/kk given)
+  // and, if DMA, this wave's eight pieces of tile t+4.  No branches: a conditional around MFMAs makes hipcc keep two
+  // register assignments of the 256 accumulators and shuffle them at the join.
+  auto kstep = [&](auto bufc, int nslot, int nkk, auto dmac, int dslot, int soffA, int soffW) {
+    constexpr int B = decltype(bufc)::value;
+    constexpr bool DMA = decltype(dmac)::value;
+    using NB = std::integral_constant<int, 1 - B>;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int i = g >> 1, j0 = (g & 1) * 2;
+      acc[j0 >> 1][i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[B][i], fb[B][j0], acc[j0 >> 1][i][0], 0, 0, 0);
+      FRAG(NB{}, nslot, nkk, g);
+      acc[j0 >> 1][i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[B][i], fb[B][j0 + 1], acc[j0 >> 1][i][1], 0, 0, 0);
+      if (DMA) dma_piece(g, dslot, soffA, soffW);
+      FENCE();
+    }
+  };
+  using T = std::true_type; using F = std::false_type;
+  using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: tiles 0..3 in flight, tile 0 complete, fragments of (0,0) ----
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int sa = koff_a(t), sw = t * KT * 2;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma_piece(q, t, sa, sw);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070 | (24 & 15) | ((24 >> 4) << 14));   // vmcnt(24): tile 0 landed (nk >= 4, launcher)
+  __builtin_amdgcn_s_barrier();
+  FENCE();
+#pragma unroll
+  for (int g = 0; g < 8; ++g) FRAG(B0{}, 0, 0, g);
+
+  // ---- main loop over K-tiles; slot = t & 3 is a compile-time constant in the 4x unrolled body.  Every tile issues the
+  //      DMA of tile t+4 (index clamped past the end: tile nk-1 is re-fetched into a slot nobody reads) and prefetches the
+  //      fragments of (t+1,0) (stale LDS past the end, never multiplied): uniform vmcnt accounting, no branches.
+  auto tile = [&](auto slotc, int t) {
+    constexpr int S = decltype(slotc)::value;
+    const int td = t + 4 < nk ? t + 4 : nk - 1;
+    const int sa = koff_a(td), sw = td * KT * 2;
+    kstep(B0{}, S, 1, F{}, 0, 0, 0);                  // step (t,0): fragments of (t,1) from this tile's slot
+    __builtin_amdgcn_s_waitcnt(0x0070 | (16 & 15) | ((16 >> 4) << 14));   // vmcnt(16) lgkmcnt(0): tile t+1 complete
+    __builtin_amdgcn_s_barrier();                     // B_t: ... everywhere, and tile t's slot is free
+    FENCE();
+    kstep(B1{}, (S + 1) & 3, 0, T{}, S, sa, sw);      // step (t,1): fragments of (t+1,0); DMA of tile t+4 into slot S
+  };
+  for (int t = 0; t < nk; t += 4) {
+    tile(std::integral_constant<int, 0>{}, t);
+    tile(std::integral_constant<int, 1>{}, t + 1);
+    tile(std::integral_constant<int, 2>{}, t + 2);
+    tile(std::integral_constant<int, 3>{}, t + 3);
+  }
+#undef FENCE
+  __syncthreads();
+
+  gemm_epilogue<4, 2, EPI>(p, acc[0], smem, wave, lane, m0 + wr * 128, n0 + wc * 128);
+  gemm_epilogue<4, 2, EPI>(p, acc[1], smem, wave, lane, m0 + wr * 128, n0 + wc * 128 + 64);
+}
+
 template <auto Kernel>
 int launch_kernel(const char* what, dim3 grid, dim3 block, int smem, hipStream_t stream, const GemmParams& p) {
   static bool attr_set = false;      // per kernel instantiation
@@ -710,6 +868,25 @@ int launch_pp(const GemmParams& p, bool conv, hipStream_t stream) {
 #undef LD_PP_LAUNCH
 }
 
+int launch_w4(const GemmParams& p, bool conv, hipStream_t stream) {
+  constexpr int SMEM = 4 * (256 + 256) * 32 * 2;   // 128 KB ring (the epilogue staging reuses it)
+  const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
+  dim3 grid(nbm * nbn), block(256);
+  const int epi = pick_epilogue(p);
+#define LD_W4_LAUNCH(CONV_, EPI_) return launch_kernel<ld_gemm_w4_kernel<CONV_, EPI_>>("ld_gemm_w4", grid, block, SMEM, stream, p)
+  if (conv) {
+    if (epi == EPI_BIAS) LD_W4_LAUNCH(true, EPI_BIAS);
+    LD_W4_LAUNCH(true, EPI_GENERIC);
+  }
+  switch (epi) {
+    case EPI_BIAS: LD_W4_LAUNCH(false, EPI_BIAS);
+    case EPI_GELU: LD_W4_LAUNCH(false, EPI_GELU);
+    case EPI_GATE: LD_W4_LAUNCH(false, EPI_GATE);
+    default: LD_W4_LAUNCH(false, EPI_GENERIC);
+  }
+#undef LD_W4_LAUNCH
+}
+
 int launch(const GemmParams& p, bool conv, hipStream_t stream) {
   // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves, 3 = 256x256 / 8 waves (both 2-stage, barrier-drained),
   // 7 = 256x256 / 8 waves ping-pong main loop
@@ -727,8 +904,9 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     cfg = (tiles256 >= 512 && (p.N >= 4096 || p.K >= 4096)) ? 3 : 1;
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
-  if (cfg != 3 && cfg != 7) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  if (cfg != 3 && cfg != 7 && cfg != 8) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
   auto big = [&](const GemmParams& q) {
+    if (cfg == 8 && pp_ok) return launch_w4(q, conv, stream);
     return (cfg == 7 && pp_ok) ? launch_pp(q, conv, stream) : launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);
   };
   // Wave quantisation: one 256x256 tile per CU at a time, so a grid of 4.3 "rounds" of 256 tiles costs 5.  When the last
