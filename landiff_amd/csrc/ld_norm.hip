@@ -213,50 +213,53 @@ __global__ __launch_bounds__(256) void ld_qkv_split_kernel(SplitParams p) {
 // squares, accumulated in double with one atomic pair per workgroup.  stats [F][G][2] must be zeroed.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ld_gn_stats_kernel(const bf16_t* x, double* stats, long P, int C, int G, int rows_per_block) {
-  __shared__ float red[2][64];      // per group partials (G <= 64)
+  // Per-thread partials are combined in a FIXED order (no floating-point atomics inside the block): the fp32 LDS atomics
+  // this replaced made the statistics differ by ~6e-7 from run to run, which a 30-layer decoder amplifies into visible
+  // last-bit noise.  Across blocks the fp64 atomics remain (order noise ~1e-16 relative).
+  __shared__ float part[2][256][4];   // [sum | sumsq][thread][sub-group of the thread's 8 channels]
   const int f = blockIdx.y;
   const long p0 = (long)blockIdx.x * rows_per_block;
   const int cpg = C / G;
   const int chunks_per_row = C >> 3;
   const int tid = threadIdx.x;
-  if (tid < 128) red[tid >> 6][tid & 63] = 0.f;
-  __syncthreads();
-  // a thread owns one 8-channel chunk column (fixed group) and strides over rows
+  // a thread owns one 8-channel chunk column and strides over rows
   const int chunk = tid % chunks_per_row;
   const int rlane = tid / chunks_per_row;
   const int rstep = 256 / chunks_per_row;
-  float s = 0.f, ss = 0.f;
+  const int nsub = cpg >= 8 ? 1 : 8 / cpg;       // groups inside one 8-channel chunk (cpg in {2,4} -> 4, 2)
+  float gs[4] = {0.f, 0.f, 0.f, 0.f}, gss[4] = {0.f, 0.f, 0.f, 0.f};
   if (rlane < rstep) {
     const long pend = min(p0 + rows_per_block, P);
     for (long r = p0 + rlane; r < pend; r += rstep) {
       const u32x4_t a = *(const u32x4_t*)(x + ((long)f * P + r) * C + chunk * 8);
+      float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float lo = bf_lo(a[e]), hi = bf_hi(a[e]); s += lo + hi; ss += lo * lo + hi * hi; }
-    }
-    const int g = (chunk * 8) / cpg;       // requires cpg % 8 == 0 or 8 % cpg == 0 handled below
-    if (cpg >= 8) {
-      atomicAdd(&red[0][g], s);
-      atomicAdd(&red[1][g], ss);
+      for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(a[e]); v[2 * e + 1] = bf_hi(a[e]); }
+      if (cpg >= 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[0] += v[e]; gss[0] += v[e] * v[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[e / cpg % 4] += v[e]; gss[e / cpg % 4] += v[e] * v[e]; }
+      }
     }
   }
-  if (cpg < 8 && rlane < rstep) {
-    // small groups (cpg in {2,4}): redo per element (rare: 64-channel tensors)
-    const long pend = min(p0 + rows_per_block, P);
-    float gs[4] = {0, 0, 0, 0}, gss[4] = {0, 0, 0, 0};
-    for (long r = p0 + rlane; r < pend; r += rstep) {
-      const bf16_t* xr = x + ((long)f * P + r) * C + chunk * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float v = bf2f(xr[e]); gs[e / cpg % 4] += v; gss[e / cpg % 4] += v * v; }
-    }
-    for (int q = 0; q < 8 / cpg; ++q) {
-      atomicAdd(&red[0][(chunk * 8) / cpg + q], gs[q]);
-      atomicAdd(&red[1][(chunk * 8) / cpg + q], gss[q]);
-    }
-  }
+  for (int q = 0; q < 4; ++q) { part[0][tid][q] = gs[q]; part[1][tid][q] = gss[q]; }
   __syncthreads();
   if (tid < G) {
-    atomicAdd(&stats[((long)f * G + tid) * 2 + 0], (double)red[0][tid]);
-    atomicAdd(&stats[((long)f * G + tid) * 2 + 1], (double)red[1][tid]);
+    // group tid <- chunks [c0, c1), sub-slot q, all row lanes, in index order
+    double s = 0.0, ss = 0.0;
+    int c0, c1, q;
+    if (cpg >= 8) { c0 = tid * (cpg >> 3); c1 = c0 + (cpg >> 3); q = 0; }
+    else { c0 = tid / nsub; c1 = c0 + 1; q = tid % nsub; }
+    for (int rl = 0; rl < rstep; ++rl)
+      for (int c = c0; c < c1; ++c) {
+        const int t = rl * chunks_per_row + c;
+        s += (double)part[0][t][q]; ss += (double)part[1][t][q];
+      }
+    atomicAdd(&stats[((long)f * G + tid) * 2 + 0], s);
+    atomicAdd(&stats[((long)f * G + tid) * 2 + 1], ss);
   }
 }
 

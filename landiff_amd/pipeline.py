@@ -33,14 +33,16 @@ class PromptInputs:
 
 
 class LanDiffPipeline:
-    def __init__(self, cfg: PipelineConfig, states: dict, device="cuda:0"):
+    def __init__(self, cfg: PipelineConfig, states: dict, device="cuda:0", max_llm_frames: int | None = None):
         if not torch.cuda.is_available():
             raise _lib.LandiffHipError("LanDiffPipeline needs an MI355X GPU: there is no CPU fallback")
         _lib.load()
         self.cfg = cfg.check()
         self.dev = torch.device(device)
         torch.cuda.set_device(self.dev)
-        self.llm = LLMRunner(states["llm"], cfg.llm, self.dev, max_frames=cfg.llm.segment_length) if "llm" in states else None
+        # max_llm_frames > segment_length sizes the KV cache / position tables for multi-segment (streaming) decodes
+        self.llm = LLMRunner(states["llm"], cfg.llm, self.dev,
+                             max_frames=max_llm_frames or cfg.llm.segment_length) if "llm" in states else None
         self.detok = Detokenizer(states["tok"], states["ups"], cfg.tok, cfg.ups, self.dev)
         self.dit = ControlDiTRunner(states["dit_main"], states["dit_control"], cfg.dit, self.dev)
         self.sampler = DiffusionSampler(cfg.sampler)
@@ -92,6 +94,68 @@ class LanDiffPipeline:
         self._t("llm", t0)
         z = self.generate_latent(tokens, inp)
         return self.decode(z, want_float=want_float)
+
+
+    # ---- streaming long video (BASELINE config 3) --------------------------------
+    def stream_plan(self, n_chunks: int, prefix_frames: int):
+        """(latent frames per chunk, new latent frames per later chunk, LLM segments needed)."""
+        T, seg = self.cfg.dit.latent_frames, self.cfg.llm.segment_length
+        new = T - prefix_frames
+        assert 0 < prefix_frames < T and new % 2 == 0, "later chunks decode their new latent frames in pairs"
+        total = T + (n_chunks - 1) * new
+        return T, new, -(-total // seg)
+
+    @torch.no_grad()
+    def generate_stream(self, inp: PromptInputs, n_chunks: int, prefix_frames: int = 7, want_float: bool = False,
+                        tokens: torch.Tensor | None = None, noises=None, randn_like=torch.randn_like):
+        """Chunked long-video generation out of the reference's streaming primitives -- the reference ships the pieces
+        (yaml :213,231 "fixed_frames: 7 # 49 frames, 13 latent, prefix_length=7"), not the loop:
+          * ONE multi-segment AR decode (Semantic1DLM.sample with num_frames = n_seg * segment_length, lm_model.py:278-291,
+            361-396): the KV cache carries over the segments, tokens never leave the device;
+          * per segment detokenize + upsample -> semantic features for all latent frames, resident in HBM;
+          * chunk c > 0: CogWrapper.forward(vae_feature_prefix = last `prefix_frames` latents of chunk c-1)
+            (dif_infer.py:159,232; diffusion_video.py:287-288) with the sampler pinning those frames
+            (sampling.py:800-835), conditioned on the semantic-feature window of its 13 latent frames;
+          * the new latent frames are decoded against the VAE's causal-conv caches of the previous chunk
+            (cp_enc_dec.py:436-466), which stay in HBM.
+        Chunk c is seeded with inp.seed + c.  Returns uint8 frames [4T-3 + (n_chunks-1)*4*new, H, W, 3] (+ fp32 video)."""
+        d, lc = self.cfg.dit, self.cfg.llm
+        T, new, n_seg = self.stream_plan(n_chunks, prefix_frames)
+        t0 = time.perf_counter()
+        if tokens is None:
+            torch.manual_seed(inp.seed); torch.cuda.manual_seed(inp.seed)
+            tokens = self.llm.sample(inp.llm_text_emb, motion_score=inp.motion_score, num_frames=n_seg * lc.segment_length,
+                                     guidance_scale=inp.cfg, temperature=1.0, seed=inp.seed)
+        self._t("llm", t0)
+        t0 = time.perf_counter()
+        per_seg = self.cfg.tok.num_latent_tokens
+        tokens = tokens.to(self.dev).reshape(n_seg, per_seg)
+        sem_all = torch.cat([self.detok.semantic_condition(tokens[s]) for s in range(n_seg)], dim=0)   # [n_seg*T, C, H, W]
+        self._t("detokenize", t0)
+        outs, vids, prev = [], [], None
+        for c in range(n_chunks):
+            t0 = time.perf_counter()
+            torch.manual_seed(inp.seed + c); torch.cuda.manual_seed(inp.seed + c)
+            self.dit.set_condition(inp.dit_context, sem_all[c * new: c * new + T].contiguous())
+            noise = noises[c].to(self.dev) if noises is not None else torch.randn(
+                1, T, d.in_channels, d.latent_h, d.latent_w, device=self.dev, dtype=torch.float32)
+            if c == 0:
+                z = self.sampler.run(self.dit.step, noise, randn_like=randn_like)
+            else:
+                z = self.sampler.run(self.dit.step, noise, randn_like=randn_like, prefix=prev[:, T - prefix_frames:],
+                                     fixed_frames=prefix_frames)
+            prev = z.to(torch.bfloat16).float()              # samples.to(self.dtype) (diffusion_video.py:314)
+            self._t("dit", t0)
+            t0 = time.perf_counter()
+            lat = prev if c == 0 else prev[:, prefix_frames:]
+            r = self.vae.decode(lat, want_float=want_float, stream_continue=c > 0, stream_keep=c < n_chunks - 1)
+            self._t("vae", t0)
+            if want_float:
+                outs.append(r[0]); vids.append(r[1])
+            else:
+                outs.append(r)
+        frames = torch.cat(outs, dim=0)
+        return (frames, torch.cat(vids, dim=1)) if want_float else frames
 
 
 def synthetic_inputs(cfg: PipelineConfig, device, n_text: int = 64, seed: int = 42) -> PromptInputs:

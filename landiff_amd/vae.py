@@ -115,25 +115,36 @@ class VAEDecoder:
 
     # ---- whole latent ------------------------------------------------------------------------
     @torch.no_grad()
-    def decode(self, latent: torch.Tensor, want_float: bool = False):
+    def decode(self, latent: torch.Tensor, want_float: bool = False, stream_continue: bool = False,
+               stream_keep: bool = False):
         """latent [1, T, C, h, w] fp32/bf16 (sampler output) -> uint8 frames [4T-3, 8h, 8w, 3] on the device
-        (+ optionally the fp32 video [3, 4T-3, 8h, 8w] in [0,1])."""
+        (+ optionally the fp32 video [3, 4T-3, 8h, 8w] in [0,1]).
+
+        Streaming: the causal-conv caches are the reference's cross-chunk state
+        (ContextParallelCausalConv3d.forward(x, clear_cache), cp_enc_dec.py:436-466).  `stream_keep` leaves them in HBM after
+        the last sub-chunk instead of clearing them; `stream_continue` decodes T *new* latent frames (T even) against the
+        caches of the previous call in sub-chunks of two -> 4T frames."""
         cfg = self.cfg
         _, Tl, C, h, w = latent.shape
         lat32 = latent.float().contiguous()
-        self.cache = {}
-        loop = (Tl - 1) // 2
-        n_frames = 4 * Tl - 3
+        if stream_continue:
+            assert self.cache, "stream_continue needs the caches of a previous decode(..., stream_keep=True)"
+            assert Tl % 2 == 0, "a continued chunk decodes latent frames in pairs"
+            spans = [(a, a + 2) for a in range(0, Tl, 2)]
+            n_frames = 4 * Tl
+        else:
+            self.cache = {}
+            spans = [((0, 3) if i == 0 else (i * 2 + 1, i * 2 + 3)) for i in range((Tl - 1) // 2)]
+            n_frames = 4 * Tl - 3
         P_total = n_frames * 8 * h * 8 * w
         frames = torch.empty(n_frames, 8 * h, 8 * w, 3, device=self.dev, dtype=torch.uint8)
         video = torch.empty(3, P_total, device=self.dev, dtype=torch.float32) if want_float else None
         f0 = 0
-        for i in range(loop):
-            a, b = (0, 3) if i == 0 else (i * 2 + 1, i * 2 + 3)
+        for i, (a, b) in enumerate(spans):
             T = b - a
             z_cl = torch.empty(T * h * w, ZQ_PAD, device=self.dev, dtype=BF)
             ops.latent_to_cl(lat32[0, a:b], z_cl, T, C, h, w, ZQ_PAD, 1.0 / cfg.scale_factor, src_tchw=True)
-            rgb, To, Ho, Wo = self.decode_chunk(z_cl, T, h, w, clear=(i == loop - 1))
+            rgb, To, Ho, Wo = self.decode_chunk(z_cl, T, h, w, clear=(i == len(spans) - 1 and not stream_keep))
             P = To * Ho * Wo
             if want_float:   # chunk-local [3][P] then scattered into [3][frames] below
                 tmp = torch.empty(3, P, device=self.dev, dtype=torch.float32)

@@ -43,3 +43,29 @@ class PipelineOracle:
         rec = self.vae.decode_latent(latent.permute(0, 2, 1, 3, 4))       # b t c h w -> b c t h w
         video = post_process(rec)[0]                                      # [3, T, H, W] in [0,1]
         return video, to_uint8_frames(video)
+
+    @torch.no_grad()
+    def stream(self, tokens, context, *, n_chunks, prefix_frames, noises, randn_like=torch.randn_like):
+        """The chunked long-video composition of the streaming primitives (see LanDiffPipeline.generate_stream): tokens
+        [n_seg * num_latent_tokens] -> (latents per chunk, video [3, frames, H, W] in [0,1], uint8 frames)."""
+        T = self.cfg.dit.latent_frames
+        new = T - prefix_frames
+        per_seg = self.cfg.tok.num_latent_tokens
+        segs = tokens.reshape(-1, per_seg)
+        sem_all = torch.cat([self.detok.semantic_cond(segs[s].reshape(1, 1, -1)) for s in range(segs.shape[0])], dim=1)
+        ctx, uc = context.float(), torch.zeros_like(context).float()
+        prev, lats, vids = None, [], []
+        for c in range(n_chunks):
+            sem = sem_all[:, c * new: c * new + T]
+            net = lambda x, idx, cx: self.dit(x, idx, cx, sem)
+            x0 = noises[c].clone()
+            if c > 0:
+                x0 = torch.cat([prev[:, T - prefix_frames:].float(), x0[:, prefix_frames:]], dim=1)   # diffusion_video.py:287-288
+            z = self.sampler.run(net, x0, ctx, uc, randn_like, None, fixed_frames=0 if c == 0 else prefix_frames)
+            prev = z.to(self.dtype)
+            lats.append(prev)
+            lat = prev if c == 0 else prev[:, prefix_frames:]
+            rec = self.vae.decode_latent(lat.permute(0, 2, 1, 3, 4), stream_continue=c > 0, stream_keep=c < n_chunks - 1)
+            vids.append(post_process(rec)[0])
+        video = torch.cat(vids, dim=1)
+        return lats, video, to_uint8_frames(video)

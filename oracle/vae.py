@@ -106,16 +106,22 @@ class VAEDecoderOracle:
         return self.causal_conv(h, p + "conv_out", clear_cache)
 
     @torch.no_grad()
-    def decode_latent(self, latent):
-        """CogWrapper.decode_latent (dif_infer.py:245-271).  latent [1, C, T, h, w] -> [1, 3, 4T-3, 8h, 8w] fp32."""
-        self.cache = {}
+    def decode_latent(self, latent, stream_continue=False, stream_keep=False):
+        """CogWrapper.decode_latent (dif_infer.py:245-271).  latent [1, C, T, h, w] -> [1, 3, 4T-3, 8h, 8w] fp32.
+        Streaming: `stream_keep` keeps the conv caches after the last sub-chunk (clear_cache=False throughout,
+        cp_enc_dec.py:436-466); `stream_continue` decodes T new latent frames in pairs against those caches -> 4T frames."""
         latent = 1.0 / self.cfg.scale_factor * latent
         T = latent.shape[2]
-        loop = (T - 1) // 2
+        if stream_continue:
+            assert self.cache and T % 2 == 0
+            spans = [(a, a + 2) for a in range(0, T, 2)]
+        else:
+            self.cache = {}
+            spans = [((0, 3) if i == 0 else (i * 2 + 1, i * 2 + 3)) for i in range((T - 1) // 2)]
         recons = []
-        for i in range(loop):
-            a, b = (0, 3) if i == 0 else (i * 2 + 1, i * 2 + 3)
-            recons.append(self.decode_chunk(latent[:, :, a:b].contiguous(), clear_cache=(i == loop - 1)))
+        for i, (a, b) in enumerate(spans):
+            recons.append(self.decode_chunk(latent[:, :, a:b].contiguous(),
+                                            clear_cache=(i == len(spans) - 1 and not stream_keep)))
         return torch.cat(recons, dim=2).to(torch.float32)
 
 

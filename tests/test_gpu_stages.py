@@ -125,6 +125,17 @@ def test_vae_decode(cuda, setup):
     assert err.max().item() < 6e-2 and err.mean().item() < 4e-3, (err.max().item(), err.mean().item())
     # uint8 frames are exactly the truncation of the float video
     assert torch.equal(frames.cpu(), to_uint8_frames(video.cpu()))
+    # streaming: the same frames come out of decode([0:3], keep caches) + decode([3:5], continue).  GroupNorm statistics
+    # are accumulated with fp64 atomics (summation order varies run to run), so "same" is up to a rare last-bit flip of
+    # a bf16 activation: at most one uint8 step on a tiny fraction of the pixels.
+    fa = vae.decode(latent[:, :3].to(cuda), stream_keep=True)
+    assert vae.cache
+    fb = vae.decode(latent[:, 3:5].to(cuda), stream_continue=True)
+    assert not vae.cache
+    diff = (torch.cat([fa, fb], dim=0).int() - frames.int()).abs()
+    assert diff.max().item() <= 2 and (diff > 0).float().mean().item() < 2e-2, (diff.max().item(), (diff > 0).float().mean().item())
+    again = (vae.decode(latent.to(cuda)).int() - frames.int()).abs()    # the run-to-run floor of the one-call decode itself
+    assert again.max().item() <= 2
 
 
 def test_llm_teacher_forced_logits_and_sampler(cuda, setup):
@@ -214,6 +225,50 @@ def test_end_to_end_tiny(cuda, setup):
     err = (video.cpu() - video32).abs().mean().item()
     assert err < max(2 * floor_v, 5e-3), (err, floor_v)
     assert frames.shape == frames_ref.shape and frames.dtype == torch.uint8
+
+
+def test_streaming_two_chunks_tiny(cuda, setup):
+    """Chunked long-video driver: one multi-segment AR decode, per-chunk sampler with the previous
+    chunk's last latents pinned as prefix, VAE decode continued against the HBM-resident conv caches -- against the
+    oracle's composition of the same reference primitives, same tokens and injected noise."""
+    from landiff_amd.pipeline import LanDiffPipeline, synthetic_inputs
+    from oracle.pipeline import PipelineOracle
+    cfg, st = setup
+    n_chunks, P = 2, 1
+    pipe = LanDiffPipeline(cfg, st, cuda, max_llm_frames=2 * cfg.llm.segment_length)
+    T, new, n_seg = pipe.stream_plan(n_chunks, P)
+    assert (T, new, n_seg) == (cfg.dit.latent_frames, cfg.dit.latent_frames - 1, 2)
+    inp = synthetic_inputs(cfg, cuda, n_text=6, seed=42)
+    torch.manual_seed(1); torch.cuda.manual_seed(1)
+    tokens = pipe.llm.sample(inp.llm_text_emb, motion_score=0.1, num_frames=n_seg * cfg.llm.segment_length,
+                             guidance_scale=7.5, seed=42)
+    assert tokens.shape == (n_seg * cfg.tok.num_latent_tokens,) and int(tokens.max()) < cfg.tok.codebook_size
+    d = cfg.dit
+    g = torch.Generator().manual_seed(11)
+    noises = [torch.randn(1, T, d.in_channels, d.latent_h, d.latent_w, generator=g) for _ in range(n_chunks)]
+    nz = [torch.randn(noises[0].shape, generator=g) for _ in range(16)]
+    it1, it2, it3 = iter(nz), iter(nz), iter(nz)
+    frames, video = pipe.generate_stream(inp, n_chunks, prefix_frames=P, want_float=True, tokens=tokens, noises=noises,
+                                         randn_like=lambda t: next(it1).to(cuda))
+    n_frames = 4 * T - 3 + (n_chunks - 1) * 4 * new
+    assert frames.shape[0] == n_frames and frames.dtype == torch.uint8 and video.shape[1] == n_frames
+    orc = PipelineOracle(cfg, st, torch.bfloat16)
+    lats, video_ref, frames_ref = orc.stream(tokens.cpu(), inp.dit_context.cpu(), n_chunks=n_chunks, prefix_frames=P,
+                                             noises=noises, randn_like=lambda t: next(it2))
+    orc32 = PipelineOracle(cfg, st, torch.float32)
+    lats32, video32, _ = orc32.stream(tokens.cpu(), inp.dit_context.cpu(), n_chunks=n_chunks, prefix_frames=P,
+                                      noises=noises, randn_like=lambda t: next(it3))
+    # the pinned prefix of chunk 1 is bit-for-bit the tail of chunk 0 (sampling.py:834-835)
+    assert torch.equal(lats[1][:, :P], lats[0][:, T - P:])
+    assert frames_ref.shape == frames.shape
+    floor_v = (video_ref - video32).abs().mean().item()
+    err = (video.cpu() - video32).abs().mean().item()
+    assert err < max(2 * floor_v, 5e-3), (err, floor_v)
+    # the continued chunk alone (frames after the first 4T-3) obeys the same bound: the conv caches carried over
+    tail = slice(4 * T - 3, n_frames)
+    err_t = (video.cpu()[:, tail] - video32[:, tail]).abs().mean().item()
+    floor_t = (video_ref[:, tail] - video32[:, tail]).abs().mean().item()
+    assert err_t < max(2 * floor_t, 5e-3), (err_t, floor_t)
 
 
 @pytest.mark.parametrize("V,top_k,top_p", [(2055, 50, None), (2055, None, 0.9), (2055, 20, 0.5), (2055, None, 0.0),

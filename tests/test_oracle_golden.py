@@ -206,6 +206,24 @@ def test_vae_chunked_decode_fp32():
 
 
 # ---------------------------------------------------------------- DiT
+def test_vae_stream_decode_equals_reference_schedule():
+    """Streaming use of the conv caches: decoding latent frames [0:5] in one call (the reference's chunk schedule 0:3, 3:5 with
+    clear_cache only on the last, dif_infer.py:245-271) must equal decode([0:3], keep caches) + decode([3:5], continue)."""
+    from landiff_amd.config import VAEConfig
+    from landiff_amd.weights import init_state, vae_spec
+    from oracle.vae import VAEDecoderOracle
+    cfg = VAEConfig.tiny()
+    orc = VAEDecoderOracle(init_state(vae_spec(cfg), 5), cfg, torch.float32)
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(1, cfg.z_channels, 7, 6, 8, generator=g)
+    whole = orc.decode_latent(lat)
+    a = orc.decode_latent(lat[:, :, :3], stream_keep=True)
+    b = orc.decode_latent(lat[:, :, 3:5], stream_continue=True, stream_keep=True)
+    c = orc.decode_latent(lat[:, :, 5:7], stream_continue=True)
+    assert not orc.cache                                   # the last call cleared the caches
+    assert torch.equal(torch.cat([a, b, c], dim=2), whole)
+
+
 def test_dit_layers_fp32():
     from landiff_amd.config import DiTConfig
     from landiff_amd.weights import dit_spec, init_state
