@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tiny", action="store_true", help="tiny random-init config (plumbing check, not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream-chunks", type=int, default=0,
+                    help="BASELINE config 3 instead of the headline config: N-chunk streaming long video (prefix 7 latent "
+                         "frames pinned per later chunk, LLM KV / latents / VAE conv caches reused in HBM)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,14 +108,21 @@ def main():
     cfg = (PipelineConfig.tiny(3) if args.tiny else PipelineConfig.full()).check()
     states = init_pipeline_state(cfg, seed=1234, dtype=torch.bfloat16, device=dev)
     # fp32 where the reference keeps fp32 parameters on the LLM path (norm gains, final LN, head, embedding table)
-    pipe = LanDiffPipeline(cfg, states, dev)
+    stream = args.stream_chunks
+    prefix = 7 if not args.tiny else 1
+    if stream:
+        T_, new_, n_seg = (cfg.dit.latent_frames, cfg.dit.latent_frames - prefix,
+                           -(-(cfg.dit.latent_frames + (stream - 1) * (cfg.dit.latent_frames - prefix)) // cfg.llm.segment_length))
+        pipe = LanDiffPipeline(cfg, states, dev, max_llm_frames=n_seg * cfg.llm.segment_length)
+    else:
+        pipe = LanDiffPipeline(cfg, states, dev)
     del states
     torch.cuda.empty_cache()
     # rank r works on prompt r (weak scaling: one prompt per GPU per step); same seed convention as a single-GPU run
     inp = synthetic_inputs(cfg, dev, n_text=64 if not args.tiny else 6, seed=42 + rank)
 
     def one_step():
-        frames = pipe(inp)
+        frames = pipe.generate_stream(inp, stream, prefix_frames=prefix) if stream else pipe(inp)
         gathered = gather_frames(frames[None], world)
         return gathered
 
@@ -149,9 +159,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("tiny random-init plumbing config" if args.tiny else
                                     "LanDiff 5B full pipeline, single prompt per GPU, 49f 480x720, 50 sampler steps "
-                                    "(VPSDE DPM-Solver++(2M), DynamicCFG), bf16, random-init weights at true shapes"),
+                                    "(VPSDE DPM-Solver++(2M), DynamicCFG), bf16, random-init weights at true shapes")
+                                   + (f"; streaming long video: {stream} chunks, {prefix} prefix latent frames pinned per later "
+                                      f"chunk, {n_frames} frames" if stream else ""),
                        "frames": n_frames, "height": 8 * d.latent_h, "width": 8 * d.latent_w,
-                       "sampler_steps": cfg.sampler.num_steps, "llm_steps": 1244 if not args.tiny else None,
+                       "sampler_steps": cfg.sampler.num_steps, "llm_steps": (1244 if not stream else None) if not args.tiny else None,
                        "parallelism": f"dp{world} over prompts, RCCL all_gather of uint8 frames only"},
             "stage_seconds_rank0": {k: round(v / args.steps, 3) for k, v in pipe.timings.items()},
             "roofline": {"kernel": "ld_attn_pipe2_kernel (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (d.heads, d.seq_len),
