@@ -202,6 +202,17 @@ int ld_to_uint8(const void* x, int64_t ldx, uint8_t* out, float* video, int64_t 
 int ld_latent_to_cl(const float* x, void* out, int64_t T, int64_t C, int64_t H, int64_t W, int64_t Cpad, float mul,
                     int32_t src_tchw, void* stream);
 
+/* ---- T5 text encoders (HF transformers T5EncoderModel called from
+ * landiff/llm/modules/text_encoder.py:36-42,82-112 and landiff/diffusion/sgm/modules/encoders/modules.py:249-292) ---- */
+
+/* T5LayerNorm (transformers modeling_t5.py): fp32 variance, bf16(x*rsqrt) then bf16(weight * that); bf16 weight. */
+int ld_t5_rmsnorm(const void* x, const void* w, void* out, int64_t rows, int64_t D, float eps, void* stream);
+
+/* T5 self-attention, head_dim 64, N <= 512: q/k/v/out [N][ld] bf16 (head h at columns 64h..64h+63), no score scaling,
+ * additive relative-position bias bias_table[bucket[j - i + N - 1]][h] (bf16 [num_buckets][H]), softmax in fp32. */
+int ld_t5_attn(const void* q, const void* k, const void* v, void* out, int64_t ld, const void* bias_table,
+               const int32_t* bucket, int64_t N, int64_t H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,8 @@ SIGNATURES: dict[str, list] = {
     "ld_place_cl": [P, P, I64, I64, I64, I64, I64, I64, I32, I32, I64, I64, I64, P],
     "ld_to_uint8": [P, I64, P, P, I64, P],
     "ld_latent_to_cl": [P, P, I64, I64, I64, I64, I64, c_float, I32, P],
+    "ld_t5_rmsnorm": [P, P, P, I64, I64, c_float, P],
+    "ld_t5_attn": [P, P, P, P, I64, P, P, I64, I64, P],
 }
 
 

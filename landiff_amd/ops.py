@@ -262,3 +262,21 @@ def to_uint8(x, out, video, P):
 def latent_to_cl(x, out, T, C, H, W, Cpad, mul, src_tchw):
     check(_lib.load().ld_latent_to_cl(_ptr(x), _ptr(out), T, C, H, W, Cpad, float(mul), int(src_tchw), _stream()),
           "ld_latent_to_cl")
+
+
+# ---- T5 text encoders -------------------------------------------------------------------------------
+def t5_rmsnorm(x, w, out, eps):
+    _bf16(x, "x"); _bf16(w, "w"); _bf16(out, "out")
+    rows, D = x.shape
+    check(_lib.load().ld_t5_rmsnorm(_ptr(x), _ptr(w), _ptr(out), rows, D, float(eps), _stream()), "ld_t5_rmsnorm")
+    return out
+
+
+def t5_attn(q, k, v, out, bias_table, bucket, H):
+    """q, k, v, out: [N, ld] bf16 views (last dim contiguous, same row stride); bucket int32 [2N-1]."""
+    N = q.shape[0]
+    ld = q.stride(0)
+    assert k.stride(0) == ld and v.stride(0) == ld and out.stride(0) == ld and bucket.dtype == torch.int32
+    check(_lib.load().ld_t5_attn(_ptr(q), _ptr(k), _ptr(v), _ptr(out), ld, _ptr(bias_table), _ptr(bucket), N, H, _stream()),
+          "ld_t5_attn")
+    return out
