@@ -28,11 +28,7 @@
 
 namespace {
 
-// LAZY: no max pre-pass.  P = exp2(S' - m_old) is formed directly, packed to bf16 and summed with v_dot2c_f32_bf16; only
-// when a lane's partial sum shows that some score outgrew the running max by more than ~2^8 (or on the first valid tile)
-// does the wave recompute S from the K tile still in LDS and rebase.  Cuts the VALU stream from ~122 to ~75 instructions
-// per 64-key tile -- the VALU port, not the matrix pipe, is what bounds this kernel (profiles/r01_attn_pmc_sq.txt).
-template <int TPS, bool DEFER, bool PRIO, bool MFMASUM, int WPS, bool LAZY = false>   // WPS = waves/SIMD of the register budget
+template <int TPS, bool DEFER, bool PRIO, bool MFMASUM, int WPS>   // WPS = waves/SIMD of the register budget
 __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x TPS x (K 8 KB + V^T 8 KB) + 64 B
   constexpr int STAGE = TPS * STAGE_BYTES;
@@ -246,67 +242,6 @@ __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
         }
     };
     if (need_mask) apply_mask();
-    if constexpr (LAZY) {
-      u32x4_t pw[4];
-      float ps;
-      auto exp_pack = [&]() {
-        ps = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float p0 = __builtin_amdgcn_exp2f(sacc[ks >> 1][(ks & 1) * 8 + 2 * e]);
-            const float p1 = __builtin_amdgcn_exp2f(sacc[ks >> 1][(ks & 1) * 8 + 2 * e + 1]);
-            const uint32_t w = pack_bf16x2(p0, p1);
-            pw[ks][e] = w;
-            // ps += lo + hi of the packed pair.  By hand: hipcc (ROCm 7.2) folds the four __builtin_amdgcn_fdot2_f32_bf16
-            // calls of one u32x4 into four reads of element 0.
-            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(ps) : "v"(0x3f803f80u), "v"(w));
-          }
-      };
-      exp_pack();
-      const bool trig = unset || !(ps <= 256.0f);          // also catches inf/NaN from a far outgrown max
-      if (!__all(!trig)) {
-        // rare: recompute S' - m_old from the K tile (still resident), find the true max and rebase
-        bf16x8_t kf2[2][4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) kf2[i][kk] = *(const bf16x8_t*)(smem + kofs[kk] + OFF + i * 4096);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf2[i][kk], qf[kk], kk == 0 ? negm : sacc[i], 0, 0, 0);
-        if (need_mask) apply_mask();
-        float mx = max3f(sacc[0][0], sacc[1][0], sacc[0][1]);
-        mx = max3f(mx, sacc[1][1], sacc[0][2]);
-#pragma unroll
-        for (int r = 2; r < 15; ++r) mx = max3f(mx, sacc[1][r], sacc[0][r + 1]);
-        mx = fmaxf(mx, sacc[1][15]);
-        mx = lane32_max(mx);
-        const bool valid = mx > -1.0e29f;
-        const float d = valid ? (unset ? mx : fmaxf(mx, 0.0f)) : 0.0f;
-        unset = unset && !valid;
-        const float alpha = __builtin_amdgcn_exp2f(-d);
-        lsum *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] -= d;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { o[i][r] *= alpha; sacc[i][r] -= d; }
-        exp_pack();
-      }
-      lsum += ps;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw[ks]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][ks], pb, o[i], 0, 0, 0);
-      }
-      return;
-    }
     // ---- online softmax (per query column; lane and lane^32 share the row) ----
     float mx = max3f(sacc[0][0], sacc[1][0], sacc[0][1]);
     mx = max3f(mx, sacc[1][1], sacc[0][2]);
@@ -402,240 +337,6 @@ __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
   }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// Software-pipelined form for the unmasked (DiT) case: inside ONE wave the QK^T MFMAs of tile j+1 are interleaved with
-// the softmax VALU work of tile j, so the matrix pipe and the VALU port both have work from the same instruction
-// stream (2 waves/SIMD; the in-order wave can only overlap the two pipes when program order alternates them).
-//   iteration j:  barrier | DMA K(j+2), V(j+1) | max(S_j) [rare rebase] | exp/sum(S_j) || S_{j+1} = K_{j+1} Q^T |
-//                 pack P_j || O += V_j P_j
-// LDS: two K slots + two V^T slots of 8 KB; K(j+2) lands in K(j)'s slot, V(j+1) in V(j-1)'s (both retired before the
-// barrier).  The last tile (the only one that can hold keys >= Nk) is peeled and masked.
-template <int MAXSPLIT>
-__global__ __launch_bounds__(256, 2) void ld_attn_pipe_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // K slot 0,1 | V^T slot 0,1
-  constexpr int VBASE = 2 * KTILE_BYTES;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int nqb = p.Npad / QB;
-  const int n = (p.Nk + KT - 1) / KT;
-
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = bid / nqb, qb = bid - bh * nqb;
-  const int b = bh / p.H, h = bh - b * p.H;
-  const bf16_t* Qb = p.Q + (long)bh * p.Npad * D;
-  const bf16_t* Kb = p.K + (long)bh * p.Npad * D;
-  const bf16_t* Vb = p.Vt + (long)bh * D * p.Npad;
-  const int q = qb * QB + wave * 32 + (lane & 31);
-  if (qb * QB >= p.Nq) return;
-
-  bf16x8_t qf[4];
-  {
-    const bf16_t* qrow = Qb + (long)q * D + hi * 8;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const u32x4_t raw = *(const u32x4_t*)(qrow + kk * 16);
-      u32x4_t sc;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) sc[e] = pack_bf16x2(bf_lo(raw[e]) * p.c, bf_hi(raw[e]) * p.c);
-      qf[kk] = __builtin_bit_cast(bf16x8_t, sc);
-    }
-  }
-
-  // LDS-DMA: waves 0,1 bring K tiles (rows = keys), waves 2,3 bring V^T tiles (rows = d); 4 x 1 KB pieces per wave
-  const bool kwave = wave < 2;
-  const bf16_t* src_base = kwave ? Kb : Vb;
-  const long tstride = kwave ? (long)KT * D : (long)KT;       // elements per tile step in the source
-  const int rstride = kwave ? D : p.Npad;
-  const bf16_t* gsrc[4];
-  int ldsoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = (wave & 1) * 4 + i;
-    const int r = piece * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-    gsrc[i] = src_base + (long)r * rstride + chunk * 8;
-    ldsoff[i] = piece * 1024;
-  }
-  auto stage = [&](int dst, int t) {          // dst: byte offset of the slot (wave-uniform), t: tile index
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(gsrc[i] + t * tstride, smem + dst + ldsoff[i]);
-  };
-
-  int kofs[4], vofs[4];
-  {
-    const int key = swap23(lane & 31);
-    const int d = lane & 31;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int c = kk * 2 + hi;
-      kofs[kk] = key * 128 + ((c ^ ((key >> 1) & 7)) << 4);
-      vofs[kk] = VBASE + d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
-    }
-  }
-
-  f32x16_t o[2], negm;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
-  float lsum = 0.f;
-  bool unset = true;
-  constexpr float THR = 8.0f;
-
-  // ---- pieces ----
-  auto load_kf = [&](auto slotc, bf16x8_t (&kf)[2][4]) {
-    constexpr int OFF = decltype(slotc)::value * KTILE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) kf[i][kk] = *(const bf16x8_t*)(smem + kofs[kk] + OFF + i * 4096);
-  };
-  auto load_vf = [&](auto slotc, bf16x8_t (&vf)[2][4]) {
-    constexpr int OFF = decltype(slotc)::value * KTILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) vf[i][ks] = *(const bf16x8_t*)(smem + vofs[ks] + OFF + i * 4096);
-  };
-  auto qk = [&](const bf16x8_t (&kf)[2][4], f32x16_t (&sn)[2]) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        sn[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][kk], qf[kk], kk == 0 ? negm : sn[i], 0, 0, 0);
-  };
-  // running-max bookkeeping for the tile held in sc (rare branch rebases everything at the old max)
-  auto rebase = [&](f32x16_t (&sc)[2]) {
-    float mx = max3f(sc[0][0], sc[1][0], sc[0][1]);
-    mx = max3f(mx, sc[1][1], sc[0][2]);
-#pragma unroll
-    for (int r = 2; r < 15; ++r) mx = max3f(mx, sc[1][r], sc[0][r + 1]);
-    mx = fmaxf(mx, sc[1][15]);
-    mx = lane32_max(mx);
-    const bool valid = mx > -1.0e29f;
-    if (!__all(!(valid && (unset || mx > THR)))) {
-      const float d = valid ? (unset ? mx : fmaxf(mx, 0.0f)) : 0.0f;
-      unset = unset && !valid;
-      const float alpha = __builtin_amdgcn_exp2f(-d);
-      lsum *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) negm[r] -= d;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o[i][r] *= alpha; sc[i][r] -= d; }
-    }
-  };
-  auto exps = [&](f32x16_t (&sc)[2]) {
-    float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float a = __builtin_amdgcn_exp2f(sc[0][r]);
-      const float c = __builtin_amdgcn_exp2f(sc[1][r]);
-      sc[0][r] = a; sc[1][r] = c;
-      ps0 += a; ps1 += c;
-    }
-    lsum += ps0 + ps1;
-  };
-  auto pv = [&](const f32x16_t (&sc)[2], const bf16x8_t (&vf)[2][4]) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4_t pw;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        pw[e] = pack_bf16x2(sc[ks >> 1][(ks & 1) * 8 + 2 * e], sc[ks >> 1][(ks & 1) * 8 + 2 * e + 1]);
-      const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pw);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][ks], pb, o[i], 0, 0, 0);
-    }
-  };
-
-  // one pipelined iteration; PAR = j & 1.  K(j+1) sits in K slot 1-PAR, V(j) in V slot PAR.
-  auto iter = [&](auto parc, f32x16_t (&sc)[2], f32x16_t (&sn)[2], int j) {
-    constexpr int PAR = decltype(parc)::value;
-    __syncthreads();
-    {
-      const int t = kwave ? j + 2 : j + 1;
-      if (t < n) stage(kwave ? PAR * KTILE_BYTES : VBASE + (1 - PAR) * KTILE_BYTES, t);
-    }
-    bf16x8_t kf[2][4], vf[2][4];
-    load_kf(std::integral_constant<int, 1 - PAR>{}, kf);
-    rebase(sc);
-    load_vf(std::integral_constant<int, PAR>{}, vf);
-    qk(kf, sn);
-    exps(sc);
-    // 8 x { 1 MFMA, 4 exp, 4 add, 1 V^T fragment read }
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    pv(sc, vf);
-  };
-
-  // ---- prologue ----
-  stage(kwave ? 0 : VBASE, 0);
-  if (kwave && n > 1) stage(KTILE_BYTES, 1);
-  __syncthreads();
-  f32x16_t sa[2], sb[2];
-  {
-    bf16x8_t kf[2][4];
-    load_kf(std::integral_constant<int, 0>{}, kf);
-    qk(kf, sa);
-  }
-  int j = 0;
-  for (; j + 2 <= n - 1; j += 2) {
-    iter(std::integral_constant<int, 0>{}, sa, sb, j);
-    iter(std::integral_constant<int, 1>{}, sb, sa, j + 1);
-  }
-  if (j < n - 1) {
-    iter(std::integral_constant<int, 0>{}, sa, sb, j);
-    ++j;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) sa[i] = sb[i];
-  }
-  // ---- last tile (j == n-1): V(j) in V slot j&1; mask keys >= Nk ----
-  __syncthreads();
-  {
-    if ((j + 1) * KT > p.Nk) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int key0 = j * KT + i * 32 + g * 16 + hi * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (key0 + e >= p.Nk) sa[i][g * 8 + e] = NEG_BIG;
-        }
-    }
-    rebase(sa);
-    bf16x8_t vf[2][4];
-    if (j & 1) load_vf(std::integral_constant<int, 1>{}, vf);
-    else load_vf(std::integral_constant<int, 0>{}, vf);
-    exps(sa);
-    pv(sa, vf);
-  }
-
-  const float ltot = lane32_sum(lsum);
-  const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
-  if (q < p.Nq) {
-    bf16_t* orow = p.O + (long)b * p.o_bs + (long)q * p.o_rs + h * D;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = i * 32 + 8 * g + 4 * hi;
-        u32x2_t w2;
-        w2[0] = pack_bf16x2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
-        w2[1] = pack_bf16x2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
-        *(u32x2_t*)(orow + d0) = w2;
-      }
-  }
-}
-
 }  // namespace
 
 int ld_attn_pipe2_launch(const AttnParams& p, dim3 grid, hipStream_t st);   // ld_attn_pipe.hip
@@ -662,7 +363,7 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   static int var = -1;
   if (var < 0) {
     // tuning knob: 0 = default (pipelined kernel of ld_attn_pipe.hip where it applies, else the plain kernel),
-    // 9 = plain kernel everywhere, 1/4/5/6/7 = experimental forms of the plain kernel
+    // 9 = plain kernel everywhere, 1 / 4 = plain kernel with row sums on the matrix pipe / lean-register 4-waves form
     const char* e = getenv("LD_ATTN_VARIANT");
     var = e ? atoi(e) : 0;
   }
@@ -671,10 +372,7 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   const int64_t nkt = (Nk + KT - 1) / KT;
   if ((var == 0 || var == 8) && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {
     return ld_attn_pipe2_launch(p, grid, st);
-  } else if (var == 5 && !fid_k) hipLaunchKernelGGL((ld_attn_pipe_kernel<0>), grid, block, 4 * KTILE_BYTES, st, p);
-  else if (var == 6) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 3, true>), grid, block, s1, st, p);
-  else if (var == 7) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 2, true>), grid, block, s1, st, p);
-  else if (var == 1) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);
+  } else if (var == 1) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);
   else if (var == 4) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 4>), grid, block, s1, st, p);
   else hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 3>), grid, block, s1, st, p);
   return ld_check_launch("ld_attn_fwd_bf16");

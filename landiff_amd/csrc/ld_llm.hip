@@ -12,6 +12,7 @@
 // not shared across waves), one wave64 per output row, activations (<= 4 x K bf16) stay in L1/L2.
 // All per-step scalars (position, token) live in device memory so the whole step is graph-capturable.
 #include "ld_common.h"
+#include <stdlib.h>
 #include "../../include/landiff_hip.h"
 
 namespace {
@@ -645,7 +646,7 @@ template <int B>
 int launch_gemv_b(const GemvParams& p, hipStream_t st) {
   if (p.w_f32) return launch_gemv_cfg<B, true, 1>(p, st);
   if (p.W2 || p.N < 4096) return launch_gemv_cfg<B, false, 1>(p, st);   // gated MLP, or few rows: keep all 256 CUs busy
-  return launch_gemv_cfg<B, false, 2>(p, st);
+  return launch_gemv_cfg<B, false, 2>(p, st);     // (one row per wave measured slower at N = 6144: 12.4 vs 11.5 us)
 }
 
 }  // namespace

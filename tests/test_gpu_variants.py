@@ -1,0 +1,70 @@
+"""The tuning-knob kernel variants (selected by environment variables that the library reads once per process) stay
+correct: each is run in a fresh process against a torch fp32 reference."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+GEMM_SNIPPET = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from landiff_amd import ops
+torch.manual_seed(0)
+dev = "cuda"
+worst = 0.0
+for (M, N, K) in [(256, 256, 128), (300, 200, 256), (1000, 1920, 384), (5000, 512, 1920), (70000, 256, 128)]:
+    a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+    a[:, 0] += torch.arange(M, device=dev).to(torch.bfloat16) * 0.01          # transposition-detecting
+    bias = torch.randn(N, device=dev).to(torch.bfloat16)
+    res = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    ref = a.float() @ w.float().t() + bias.float()
+    for kw, r in ((dict(bias=bias), ref), (dict(bias=bias, act="gelu_tanh"), torch.nn.functional.gelu(ref.to(torch.bfloat16).float(), approximate="tanh")),
+                  (dict(bias=bias, resid=res), res.float() + ref.to(torch.bfloat16).float())):
+        out = ops.gemm(a, w, **kw)
+        worst = max(worst, ((out.float() - r).abs().max() / (r.abs().max() + 1e-6)).item())
+print("WORST", worst)
+''' % ROOT
+
+ATTN_SNIPPET = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from landiff_amd import ops
+torch.manual_seed(0)
+worst = 0.0
+for (B, H, N) in [(1, 2, 1122), (2, 1, 1400), (1, 1, 2175)]:
+    q = torch.randn(B, H, N, 64).cuda().bfloat16(); k = torch.randn(B, H, N, 64).cuda().bfloat16(); v = torch.randn(B, H, N, 64).cuda().bfloat16()
+    Npad = (N + 127) // 128 * 128
+    def pack(x):
+        o = torch.zeros(B, H, Npad, 64, device="cuda", dtype=x.dtype); o[:, :, :N] = x; return o
+    out = torch.zeros(B, N, H * 64, device="cuda", dtype=torch.bfloat16)
+    ops.attn_fwd(pack(q), pack(k), pack(v).transpose(2, 3).contiguous(), out, N, N, 0.125)
+    s = (q.float() @ k.float().transpose(-1, -2)) * 0.125
+    ref = (torch.softmax(s, -1) @ v.float()).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+    worst = max(worst, (out.float() - ref).abs().max().item())
+print("WORST", worst)
+''' % ROOT
+
+
+def _run(snippet, env):
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", snippet], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("WORST")][-1]
+    return float(line.split()[1])
+
+
+@pytest.mark.parametrize("env", [{"LD_GEMM_TILE": "7"}, {"LD_GEMM_TILE": "8"}, {"LD_GEMM_TILE": "3", "LD_GEMM_MSPLIT": "0"},
+                                 {"LD_GEMM_TILE": "1"}])
+def test_gemm_main_loop_variants(cuda, env):
+    assert _run(GEMM_SNIPPET, env) < 1e-2
+
+
+@pytest.mark.parametrize("env", [{"LD_ATTN_SAFE": "1"}, {"LD_ATTN_VARIANT": "9"}, {"LD_ATTN_VARIANT": "1"}, {"LD_ATTN_VARIANT": "4"}])
+def test_attention_variants(cuda, env):
+    assert _run(ATTN_SNIPPET, env) < 2e-2
