@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256) void ld_kv_attn_kernel(const bf16_t* q, const 
 // If qkv != nullptr the kernel also does apply_rope + the KV append of the current token itself (q is then ignored):
 // every workgroup rotates q on the fly; the workgroup whose key range holds position *pos rotates/stores the new k
 // and v into the cache before using them.
+constexpr int KV_MAXIT = 16;     // trips of 16 keys per workgroup: a split covers at most 256 keys
 __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, const bf16_t* qkv, const float* cos_t,
                                                                const float* sin_t, bf16_t* kc, bf16_t* vc,
                                                                const int* pos_ptr, float* ws, int B, int H, int Lmax, int nsplit) {
@@ -446,20 +447,33 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
     for (int e = 0; e < 4; ++e) { qreg[2 * e] = bf_lo(a[e]); qreg[2 * e + 1] = bf_hi(a[e]); }
   }
   const float inv_sqrt_d = 0.08838834764831845f;
-  float lmax = -3.0e38f;
-  for (int k0 = wave * 4; k0 < n; k0 += 16) {
-    const int kk = k0 + kq;
-    float d = 0.f;
-    if (kk < n) {
-      const u32x4_t a = *(const u32x4_t*)(kc + (((long)b * Lmax + k_begin + kk) * H + h) * D + sub * 8);
+  // Memory-level parallelism: a wave's K rows AND V rows (4 keys per trip, <= KV_MAXIT trips) are all requested before
+  // anything is computed -- one exposed memory latency per launch instead of one per trip (the trip-at-a-time loop this
+  // replaces spent ~10 us per launch waiting on ~20 dependent round trips).
+  u32x4_t kr[KV_MAXIT], vr[KV_MAXIT];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { d = fmaf(qreg[2 * e], bf_lo(a[e]), d); d = fmaf(qreg[2 * e + 1], bf_hi(a[e]), d); }
-    }
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+  for (int it = 0; it < KV_MAXIT; ++it) {
+    const int kk = wave * 4 + it * 16 + kq;
+    kr[it] = (u32x4_t){0u, 0u, 0u, 0u}; vr[it] = (u32x4_t){0u, 0u, 0u, 0u};
     if (kk < n) {
-      const float s = rbf(rbf(d) * inv_sqrt_d);
-      if (sub == 0) sc[kk] = s;
-      lmax = fmaxf(lmax, s);
+      const long off = (((long)b * Lmax + k_begin + kk) * H + h) * D + sub * 8;
+      kr[it] = __builtin_nontemporal_load((const u32x4_t*)(kc + off));
+      vr[it] = __builtin_nontemporal_load((const u32x4_t*)(vc + off));
+    }
+  }
+  float lmax = -3.0e38f;
+  float sreg[KV_MAXIT];
+#pragma unroll
+  for (int it = 0; it < KV_MAXIT; ++it) {
+    const int kk = wave * 4 + it * 16 + kq;
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d = fmaf(qreg[2 * e], bf_lo(kr[it][e]), d); d = fmaf(qreg[2 * e + 1], bf_hi(kr[it][e]), d); }
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+    sreg[it] = -3.0e38f;
+    if (kk < n) {
+      sreg[it] = rbf(rbf(d) * inv_sqrt_d);
+      lmax = fmaxf(lmax, sreg[it]);
     }
   }
   lmax = wave_max(lmax);
@@ -470,14 +484,14 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   float lsum = 0.f;
-  for (int k0 = wave * 4; k0 < n; k0 += 16) {
-    const int kk = k0 + kq;
-    if (kk < n) {
-      const float pk = __expf(sc[kk] - mx);
-      if (sub == 0) lsum += pk;
-      const u32x4_t a = *(const u32x4_t*)(vc + (((long)b * Lmax + k_begin + kk) * H + h) * D + sub * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { acc[2 * e] = fmaf(pk, bf_lo(a[e]), acc[2 * e]); acc[2 * e + 1] = fmaf(pk, bf_hi(a[e]), acc[2 * e + 1]); }
+  for (int it = 0; it < KV_MAXIT; ++it) {
+    const int kk = wave * 4 + it * 16 + kq;
+    if (kk < n) {
+      const float pk = __expf(sreg[it] - mx);
+      if (sub == 0) lsum += pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] = fmaf(pk, bf_lo(vr[it][e]), acc[2 * e]); acc[2 * e + 1] = fmaf(pk, bf_hi(vr[it][e]), acc[2 * e + 1]); }
     }
   }
   // reduce over the 4 key groups of a wave (lanes sub, sub+16, sub+32, sub+48), then over waves via LDS
@@ -711,6 +725,8 @@ LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cach
   if (m == 1 && nsplit > 1) {
     LD_REQUIRE(workspace, "ld_llm_kv_attn: split path needs a workspace of B*H*nsplit*130 floats");
     LD_REQUIRE(!qkv_fused || (cos_t && sin_t), "ld_llm_kv_attn: fused RoPE needs the cos/sin tables");
+    LD_REQUIRE((Lmax + nsplit - 1) / nsplit <= 16 * KV_MAXIT, "ld_llm_kv_attn: Lmax=%ld needs nsplit >= %ld (<= 256 keys per split)",
+               (long)Lmax, (long)((Lmax + 255) / 256));
     const size_t chunk = (size_t)((Lmax + nsplit - 1) / nsplit + 16);
     const size_t smem = (chunk + 8 + 4 * 128) * sizeof(float);
     hipLaunchKernelGGL(ld_kv_attn_split_kernel, dim3((unsigned)(B * H), (unsigned)nsplit), dim3(256), smem, st,

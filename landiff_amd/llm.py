@@ -114,7 +114,8 @@ class LLMRunner:
         self.logits = e(B, c.vocab, dt=torch.float32)
         self.probs = e(1, c.vocab, dt=torch.float32)
         self.cfg_logits = e(1, c.vocab, dt=torch.float32)
-        self.nsplit = max(1, 256 // (B * H))
+        # split-K decode attention: >= one workgroup per CU, and at most 256 keys per split (ld_llm_kv_attn)
+        self.nsplit = max(1, 256 // (B * H), -(-self.Lmax // 256))
         self.top_k, self.top_p = None, None
         self.attn_ws = e(B * H * self.nsplit * 130, dt=torch.float32)
         self._graph = None
