@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
 
 }  // namespace
 
-int ld_attn_pipe2_launch(const AttnParams& p, dim3 grid, hipStream_t st);   // ld_attn_pipe.hip
+int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st);   // ld_attn_pipe.hip
 
 LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
                             int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
@@ -371,7 +371,7 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   const size_t s1 = 2 * STAGE_BYTES + 64;
   const int64_t nkt = (Nk + KT - 1) / KT;
   if ((var == 0 || var == 8) && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {
-    return ld_attn_pipe2_launch(p, grid, st);
+    return ld_attn_pipe2_launch(p, st);
   } else if (var == 1) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);
   else if (var == 4) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 4>), grid, block, s1, st, p);
   else hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 3>), grid, block, s1, st, p);

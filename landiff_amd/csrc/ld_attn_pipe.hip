@@ -40,14 +40,16 @@ namespace {
 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
-__global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int force_safe) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // K slots 0..3 | V^T slots 0..3 | 4 flag words
+template <int NW>     // waves per workgroup (32 query rows each): 4 (two workgroups per CU) or 8 (one)
+__device__ __forceinline__ void attn_pipe2_body(const AttnParams& p, int force_safe, char* smem) {   // smem: K slots 0..3 | V^T slots 0..3 | NW flag words
   constexpr int VBASE = 4 * KTILE_BYTES;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5;
-  const int nqb = p.Npad / QB;
+  constexpr int QBW = NW * 32;                    // query rows per workgroup
+  constexpr int NPW = 16 / NW;                    // LDS-DMA pieces per wave and tile (K: 8 pieces, V^T: 8 pieces)
+  const int nqb = (p.Npad + QBW - 1) / QBW;
   const int n = (p.Nk + KT - 1) / KT;             // >= 6 and (n - 2) % 4 == 0 (launcher)
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -56,12 +58,12 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
   const bf16_t* Qb = p.Q + (long)bh * p.Npad * D;
   const bf16_t* Kb = p.K + (long)bh * p.Npad * D;
   const bf16_t* Vb = p.Vt + (long)bh * D * p.Npad;
-  const int q = qb * QB + wave * 32 + (lane & 31);
-  if (qb * QB >= p.Nq) return;
+  const int q = qb * QBW + wave * 32 + (lane & 31);
+  if (qb * QBW >= p.Nq) return;
 
   bf16x8_t qf[4];
   {
-    const bf16_t* qrow = Qb + (long)q * D + hi * 8;
+    const bf16_t* qrow = Qb + (long)(q < p.Npad ? q : p.Npad - 1) * D + hi * 8;   // rows past Npad (NW = 8) are never stored
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const u32x4_t raw = *(const u32x4_t*)(qrow + kk * 16);
@@ -72,17 +74,18 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
     }
   }
 
-  // LDS-DMA: waves 0,1 bring K tiles (rows = keys), waves 2,3 bring V^T tiles (rows = d); 4 x 1 KB pieces per wave and tile
-  const bool kwave = wave < 2;
+  // LDS-DMA: the first half of the waves brings K tiles (rows = keys), the second half V^T tiles (rows = d); NPW x 1 KB
+  // pieces per wave and tile
+  const bool kwave = wave < NW / 2;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)(kwave ? Kb : Vb), 0, 0x7fffffff, 0x00020000);   // raw buffer, wave-uniform
   const int tstride = kwave ? KT * D * 2 : KT * 2;               // bytes per tile step in the source
   const int rstride = kwave ? D : p.Npad;
-  uint32_t goff[4];
-  int ldsoff[4];
+  uint32_t goff[NPW];
+  int ldsoff[NPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = (wave & 1) * 4 + i;
+  for (int i = 0; i < NPW; ++i) {
+    const int piece = (wave % (NW / 2)) * NPW + i;
     const int r = piece * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((r >> 1) & 7);
     goff[i] = (uint32_t)(r * rstride + chunk * 8) * 2u;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
   };
   auto dma = [&](int slot, int t) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(i, slot, t);
+    for (int i = 0; i < NPW; ++i) dma_piece(i, slot, t);
   };
 
   int kofs[4], vofs[4];
@@ -209,14 +212,17 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
         if (FAST && MSUM) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8_t, pw[ks]), acc0, 0, 0, 0);
       };
       // ---- QK^T of tile j+1 over exp2 of the first 32 keys of tile j ----
-      QK(0); EXP2(0, 0);  VF(0); if (do_dma) dma_piece(0, dslot0, dt0); FENCE();
-      QK(1); EXP2(0, 2);  VF(1); if (do_dma) dma_piece(1, dslot0, dt0); FENCE();
-      QK(2); EXP2(0, 4);  VF(2); if (do_dma) dma_piece(2, dslot0, dt0); FENCE();
-      QK(3); EXP2(0, 6);  VF(3); if (do_dma) dma_piece(3, dslot0, dt0); FENCE();
-      QK(4); EXP2(0, 8);  VF(4); if (do_dma) dma_piece(0, dslot1, dt1); FENCE();
-      QK(5); EXP2(0, 10); VF(5); if (do_dma) dma_piece(1, dslot1, dt1); FENCE();
-      QK(6); EXP2(0, 12); VF(6); CVT2(0, 0); if (do_dma) dma_piece(2, dslot1, dt1); FENCE();
-      QK(7); EXP2(0, 14); VF(7); CVT2(0, 2); if (do_dma) dma_piece(3, dslot1, dt1); FENCE();
+      auto DMA = [&](int g) {                 // gap g of an even main-loop iteration: piece g of the period's 2 * NPW
+        if (do_dma && g < 2 * NPW) dma_piece(g % NPW, g < NPW ? dslot0 : dslot1, g < NPW ? dt0 : dt1);
+      };
+      QK(0); EXP2(0, 0);  VF(0); DMA(0); FENCE();
+      QK(1); EXP2(0, 2);  VF(1); DMA(1); FENCE();
+      QK(2); EXP2(0, 4);  VF(2); DMA(2); FENCE();
+      QK(3); EXP2(0, 6);  VF(3); DMA(3); FENCE();
+      QK(4); EXP2(0, 8);  VF(4); DMA(4); FENCE();
+      QK(5); EXP2(0, 10); VF(5); DMA(5); FENCE();
+      QK(6); EXP2(0, 12); VF(6); CVT2(0, 0); DMA(6); FENCE();
+      QK(7); EXP2(0, 14); VF(7); CVT2(0, 2); DMA(7); FENCE();
       if (MASK) mask_tail(sn, j + 1);
       if (FAST && MSUM) {
         // ---- PV + row sums (12 MFMAs) over exp2 of the last 32 keys ----
@@ -297,7 +303,9 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
     const bool wbad = __any(bad);
     if (lane == 0) flags[wave] = wbad ? 1 : 0;
     __syncthreads();
-    redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+    redo = false;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) redo = redo || flags[w] != 0;
     __syncthreads();
   }
   if (redo) ltot = pass(F{});
@@ -319,16 +327,31 @@ __global__ __launch_bounds__(256, 2) void ld_attn_pipe2_kernel(AttnParams p, int
 }
 #undef FENCE
 
+// (non-template entry points: hipcc emitted no host stub for the kernel when it was itself the template)
+__global__ __launch_bounds__(256, 2) void ld_attn_pipe2_w4_kernel(AttnParams p, int force_safe) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_pipe2_body<4>(p, force_safe, smem);
+}
+__global__ __launch_bounds__(512, 2) void ld_attn_pipe2_w8_kernel(AttnParams p, int force_safe) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_pipe2_body<8>(p, force_safe, smem);
+}
+
 }  // namespace
 
-// LD_ATTN_SAFE=1 forces the running-max pass (testing / A-B timing).
-int ld_attn_pipe2_launch(const AttnParams& p, dim3 grid, hipStream_t st) {
+// LD_ATTN_SAFE=1 forces the running-max pass (testing / A-B timing); LD_ATTN_NW=4|8 picks the workgroup size.
+int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st) {
   constexpr int SMEM = 8 * KTILE_BYTES + 64;
-  static int safe = -1;
+  static int safe = -1, nw = 4;       // 8-wave workgroups halve the K/V traffic per CU but measure the same (4.44 vs 4.46 ms)
   if (safe < 0) {
     const char* e = getenv("LD_ATTN_SAFE"); safe = e ? atoi(e) : 0;
-    (void)hipFuncSetAttribute((const void*)ld_attn_pipe2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    const char* w = getenv("LD_ATTN_NW"); if (w && atoi(w) == 8) nw = 8;
+    (void)hipFuncSetAttribute((const void*)ld_attn_pipe2_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute((const void*)ld_attn_pipe2_w8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
-  hipLaunchKernelGGL(ld_attn_pipe2_kernel, grid, dim3(256), SMEM, st, p, safe);
+  const int qbw = nw * 32;
+  dim3 grid((unsigned)((long)p.B * p.H * ((p.Npad + qbw - 1) / qbw)));
+  if (nw == 4) hipLaunchKernelGGL(ld_attn_pipe2_w4_kernel, grid, dim3(256), SMEM, st, p, safe);
+  else hipLaunchKernelGGL(ld_attn_pipe2_w8_kernel, grid, dim3(512), SMEM, st, p, safe);
   return ld_check_launch("ld_attn_fwd_bf16(pipe2)");
 }
