@@ -117,3 +117,35 @@ def test_llm_full_size_decode_properties(cuda):
     assert torch.equal(t1, t3)                                   # eager and HIP-graph paths agree bit for bit
     t4 = run.sample(text, guidance_scale=7.5, seed=43)
     assert not torch.equal(t1, t4)
+
+
+def test_dit_layer_full_shape_vs_oracle(cuda):
+    """One AdaLN layer of the main DiT at the BASELINE shape (B=2 CFG pair, 17 776 tokens, hidden 1920, 30 heads) through
+    the HIP path -- pipelined attention kernel, specialised GEMM epilogues, M-split launches -- against the fp32 oracle on
+    the host cores (the same call bench.py's cpu_baseline times, ~10 s)."""
+    import dataclasses
+    from landiff_amd.config import PipelineConfig
+    from landiff_amd.dit import ControlDiTRunner
+    from landiff_amd.weights import dit_spec, init_state
+    from oracle.dit import DiTOracle
+    d1 = dataclasses.replace(PipelineConfig.full().dit, layers_main=1, layers_control=1)
+    sd_main = init_state(dit_spec(d1, False), 1)
+    sd_ctrl = init_state(dit_spec(d1, True), 2)
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn(2, d1.seq_len, d1.hidden, generator=g).to(torch.bfloat16)
+    emb = torch.randn(2, d1.time_embed_dim, generator=g).to(torch.bfloat16)
+    torch.set_num_threads(min(64, torch.get_num_threads() * 8))
+    with torch.no_grad():
+        ref = DiTOracle(sd_main, d1, False, torch.float32).layer(0, h.float(), emb.float())
+    run = ControlDiTRunner(sd_main, sd_ctrl, d1, cuda)
+    run.emb.copy_(emb.to(cuda))
+    h_dev = h.to(cuda).reshape(-1, d1.hidden).contiguous()
+    out = torch.empty_like(h_dev)
+    run._layer(run.main, 0, h_dev, out)
+    got = out.view(2, d1.seq_len, d1.hidden).float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    scale = ref.abs().max().item()
+    # bf16 activations through LN -> QKV -> attention -> gated residual -> MLP: a few bf16 ulps of the output range
+    assert err.max().item() / scale < 3e-2, (err.max().item(), scale)
+    assert err.mean().item() / ref.abs().mean().item() < 1e-2, (err.mean().item(), ref.abs().mean().item())
