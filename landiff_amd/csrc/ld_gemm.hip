@@ -896,12 +896,14 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     const char* g = getenv("LD_GEMM_GROUP_M"); if (g && atoi(g) > 0) group_m = atoi(g);
   }
   const_cast<GemmParams&>(p).group_m = group_m;
-  // measured on MI355X (tools/microbench.py): the 256x256 tile wins once there are >= ~20 column tiles or a long K
-  // (L2->LDS traffic halves), the 128x128 tile (2 workgroups/CU) wins for narrow outputs and small problems
+  // measured on MI355X (tools/gemm_dit_shapes.py): the 256x256 tile wins once the grid fills the chip twice over
+  // (L2->LDS traffic halves); the 128x128 tile (2 workgroups/CU) is for small problems.  A 128x256-tile, two-workgroups-
+  // per-CU form of the pipelined loop (epilogue of one workgroup under the main loop of the other) measured 10 % slower
+  // than the 256x256 tile on all four DiT shapes and was dropped.
   int cfg = forced;
   if (cfg == 0) {
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    cfg = (tiles256 >= 512 && (p.N >= 4096 || p.K >= 4096)) ? 3 : 1;
+    cfg = (tiles256 >= 512 && p.K >= 1024) ? 3 : 1;     // (the DiT's 1920x1920 GEMMs: 256x256 tiles 0.26 ms vs 0.29 ms on 128x128)
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
   if (cfg != 3 && cfg != 7 && cfg != 8) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
