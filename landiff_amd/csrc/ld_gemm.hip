@@ -754,12 +754,15 @@ __global__ __launch_bounds__(256, 1) void ld_gemm_w4_kernel(GemmParams p) {
     constexpr int B = decltype(bufc)::value;
     constexpr bool DMA = decltype(dmac)::value;
     using NB = std::integral_constant<int, 1 - B>;
+    // the 8 fragment reads go behind the first four MFMA pairs (two each): their LDS latency is covered by the remaining
+    // MFMAs of this k-step instead of stalling the first MFMA of the next one
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       const int i = g >> 1, j0 = (g & 1) * 2;
       acc[j0 >> 1][i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[B][i], fb[B][j0], acc[j0 >> 1][i][0], 0, 0, 0);
-      FRAG(NB{}, nslot, nkk, g);
+      if (g < 4) FRAG(NB{}, nslot, nkk, 2 * g);
       acc[j0 >> 1][i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[B][i], fb[B][j0 + 1], acc[j0 >> 1][i][1], 0, 0, 0);
+      if (g < 4) FRAG(NB{}, nslot, nkk, 2 * g + 1);
       if (DMA) dma_piece(g, dslot, soffA, soffW);
       FENCE();
     }
