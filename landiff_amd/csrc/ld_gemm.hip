@@ -809,6 +809,155 @@ __global__ __launch_bounds__(256, 1) void ld_gemm_w4_kernel(GemmParams p) {
   gemm_epilogue<4, 2, EPI>(p, acc[1], smem, wave, lane, m0 + wr * 128, n0 + wc * 128 + 64);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-staged form of the one-wave-per-SIMD main loop (experiment for the LDS-feeding loss measured on
+// ld_gemm_w4_kernel, profiles/r01d_gemm_vs_vendor_library.txt): 256x256 tile, 4 waves x 128x128, K-tiles 64 deep on full
+// 128-byte lines.  Global memory -> VGPRs by buffer_load_dwordx4 (row offsets in SGPRs, out-of-range rows read as zero
+// through the buffer descriptor's bounds check), two register sets = prefetch three K-tiles ahead; VGPRs -> LDS by
+// ds_write_b128 one tile ahead into a two-slot ring (2 x 64 KB, XOR-swizzled 16-byte chunks as in ld_gemm_kernel).
+//   tile t:  k-steps 0,1: 16 MFMA each + ds_write of K-tile t+1 (8 per k-step)     [its slot was last read in tile t-1]
+//            k-step  2  : 16 MFMA + first half of the loads of K-tile t+3
+//            lgkmcnt(0) + barrier: K-tile t+1 visible everywhere, and nobody reads slot t&1 past k-step 3's registers
+//            k-step  3  : 16 MFMA + second half of the loads; fragment prefetch of (t+1, 0)
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void ld_gemm_w4r_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, KT = 64;
+  constexpr int A_BYTES = BM * KT * 2;              // 32 KB
+  constexpr int SLOT = (BM + BN) * KT * 2;          // 64 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, nbm * nbn);
+  const int gm_sz = p.group_m;
+  const int per_group = gm_sz * nbn;
+  const int group = bid / per_group, in_group = bid - group * per_group;
+  const int first_m = group * gm_sz;
+  const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+  const int m0 = p.m_begin + (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
+
+  // this wave stages rows [wave*64, wave*64+64) of the A tile and of the W tile: 8 + 8 loads of 8 rows x 128 B per K-tile
+  const long ldab = p.lda * 2, ldwb = (long)p.K * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (long)m0 * ldab), 0,
+      (int)(((long)(p.M - m0) * ldab) < 0x7fffffffL ? ((long)(p.M - m0) * ldab) : 0x7fffffffL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + (long)n0 * ldwb), 0,
+      (int)(((long)(p.N - n0) * ldwb) < 0x7fffffffL ? ((long)(p.N - n0) * ldwb) : 0x7fffffffL), 0x00020000);
+  const int rl = lane >> 3, cl = lane & 7;                         // row within the 8-row group, 16-byte chunk
+  const uint32_t voA = (uint32_t)((wave * 64 + rl) * ldab + cl * 16);
+  const uint32_t voW = (uint32_t)((wave * 64 + rl) * ldwb + cl * 16);
+  const int sa8 = (int)(8 * ldab), sw8 = (int)(8 * ldwb);          // SGPR step between a wave's 8-row groups
+  // LDS write addresses: row = wave*64 + i*8 + rl, chunk cl ^ ((row >> 1) & 7); (row>>1)&7 alternates with i's parity
+  int wrofs[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int row = wave * 64 + par * 8 + rl;
+    wrofs[par] = row * 128 + ((cl ^ ((row >> 1) & 7)) << 4);
+  }
+  const int nk = p.K / KT;
+
+  u32x4_t st[2][16];           // two staging sets: K-tile tau lives in set tau & 1 (loads 0-7: A groups, 8-15: W groups)
+  auto LOAD = [&](auto setc, int q, int kt) {
+    constexpr int U = decltype(setc)::value;
+    if (q < 8) st[U][q] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA, kt * (KT * 2) + q * sa8, 0);
+    else st[U][q] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW, kt * (KT * 2) + (q - 8) * sw8, 0);
+  };
+  auto WRITE = [&](auto setc, int slot, int q) {
+    constexpr int U = decltype(setc)::value;
+    const int i = q & 7;
+    char* dst = smem + slot * SLOT + (q < 8 ? 0 : A_BYTES) + wrofs[i & 1] + (i >> 1) * 2048;
+    *(u32x4_t*)dst = st[U][q];
+  };
+
+  f32x16_t acc[2][4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+  int rdA[4], rdB[4];          // fragment read offsets inside a slot for the four k-steps (+4096 B per further 32 rows)
+  {
+    const int ra = wr * 128 + (lane & 31), rb = wc * 128 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = kk * 2 + (lane >> 5);
+      rdA[kk] = ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4);
+      rdB[kk] = A_BYTES + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4);
+    }
+  }
+  bf16x8_t fa[2][4], fb[2][4];
+  auto FRAG = [&](auto bufc, int slot, int kk, int g) {
+    constexpr int B = decltype(bufc)::value;
+    if (g < 4) fa[B][g] = *(const bf16x8_t*)(smem + rdA[kk] + slot * SLOT + g * 4096);
+    else fb[B][g - 4] = *(const bf16x8_t*)(smem + rdB[kk] + slot * SLOT + (g - 4) * 4096);
+  };
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one k-step: 16 MFMAs on fragment set B, the 8 fragment reads of the next k-step behind the first four pairs, and one
+  // staging operation per pair: MODE 1 = ds_write of set U pieces q0..q0+7, MODE 2 = loads of K-tile lkt into set U
+  auto kstep = [&](auto bufc, int nslot, int nkk, auto modec, auto setc, int q0, int wslot, int lkt) {
+    constexpr int B = decltype(bufc)::value;
+    constexpr int MODE = decltype(modec)::value;
+    using NB = std::integral_constant<int, 1 - B>;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int i = g >> 1, j0 = (g & 1) * 2;
+      acc[j0 >> 1][i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[B][i], fb[B][j0], acc[j0 >> 1][i][0], 0, 0, 0);
+      if (g < 4) FRAG(NB{}, nslot, nkk, 2 * g);
+      acc[j0 >> 1][i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[B][i], fb[B][j0 + 1], acc[j0 >> 1][i][1], 0, 0, 0);
+      if (g < 4) FRAG(NB{}, nslot, nkk, 2 * g + 1);
+      if (MODE == 1) WRITE(setc, wslot, q0 + g);
+      if (MODE == 2) LOAD(setc, q0 + g, lkt);
+      FENCE();
+    }
+  };
+  using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
+  using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
+
+  // ---- prologue: K-tiles 0, 1, 2 requested; K-tile 0 -> slot 0; fragments of (0,0) ----
+#pragma unroll
+  for (int q = 0; q < 16; ++q) LOAD(B0{}, q, 0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) LOAD(B1{}, q, 1 < nk ? 1 : 0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) WRITE(B0{}, 0, q);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) LOAD(B0{}, q, 2 < nk ? 2 : 0);
+  __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0) only (vmcnt / expcnt fields at "no wait")
+  __builtin_amdgcn_s_barrier();
+  FENCE();
+#pragma unroll
+  for (int g = 0; g < 8; ++g) FRAG(B0{}, 0, 0, g);
+
+  // tile t in slot S = t & 1; set U = (t + 1) & 1 holds K-tile t+1 on entry and receives K-tile t+3
+  auto tile = [&](auto slotc, int t) {
+    constexpr int S = decltype(slotc)::value;
+    using U = std::integral_constant<int, 1 - S>;
+    const int lkt = t + 3 < nk ? t + 3 : nk - 1;      // past the end: a re-fetch that is never multiplied
+    kstep(B0{}, S, 1, M1{}, U{}, 0, 1 - S, 0);        // k-step 0: fragments of (t,1); ds_write pieces 0-7 of K-tile t+1
+    kstep(B1{}, S, 2, M1{}, U{}, 8, 1 - S, 0);        // k-step 1: fragments of (t,2); ds_write pieces 8-15
+    kstep(B0{}, S, 3, M2{}, U{}, 0, 0, lkt);          // k-step 2: fragments of (t,3); loads 0-7 of K-tile t+3
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's ds_writes and fragment reads retired
+    __builtin_amdgcn_s_barrier();
+    FENCE();
+    kstep(B1{}, 1 - S, 0, M2{}, U{}, 8, 0, lkt);      // k-step 3: fragments of (t+1,0); loads 8-15
+  };
+  for (int t = 0; t < nk; t += 2) {
+    tile(std::integral_constant<int, 0>{}, t);
+    tile(std::integral_constant<int, 1>{}, t + 1);
+  }
+#undef FENCE
+  __syncthreads();
+
+  gemm_epilogue<4, 2, EPI>(p, acc[0], smem, wave, lane, m0 + wr * 128, n0 + wc * 128);
+  gemm_epilogue<4, 2, EPI>(p, acc[1], smem, wave, lane, m0 + wr * 128, n0 + wc * 128 + 64);
+}
+
 template <auto Kernel>
 int launch_kernel(const char* what, dim3 grid, dim3 block, int smem, hipStream_t stream, const GemmParams& p) {
   static bool attr_set = false;      // per kernel instantiation
@@ -890,9 +1039,22 @@ int launch_w4(const GemmParams& p, bool conv, hipStream_t stream) {
 #undef LD_W4_LAUNCH
 }
 
+int launch_w4r(const GemmParams& p, hipStream_t stream) {
+  constexpr int SMEM = 2 * (256 + 256) * 64 * 2;   // two 64 KB K-tile slots (the epilogue staging reuses them)
+  const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
+  dim3 grid(nbm * nbn), block(256);
+  switch (pick_epilogue(p)) {
+    case EPI_BIAS: return launch_kernel<ld_gemm_w4r_kernel<EPI_BIAS>>("ld_gemm_w4r", grid, block, SMEM, stream, p);
+    case EPI_GELU: return launch_kernel<ld_gemm_w4r_kernel<EPI_GELU>>("ld_gemm_w4r", grid, block, SMEM, stream, p);
+    case EPI_GATE: return launch_kernel<ld_gemm_w4r_kernel<EPI_GATE>>("ld_gemm_w4r", grid, block, SMEM, stream, p);
+    default: return launch_kernel<ld_gemm_w4r_kernel<EPI_GENERIC>>("ld_gemm_w4r", grid, block, SMEM, stream, p);
+  }
+}
+
 int launch(const GemmParams& p, bool conv, hipStream_t stream) {
   // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves, 3 = 256x256 / 8 waves (both 2-stage, barrier-drained),
-  // 7 = 256x256 / 8 waves ping-pong main loop
+  // 7 = 256x256 / 8 waves ping-pong main loop, 8 = 4 waves LDS-DMA pipelined, 11 = 4 waves register-staged (default
+  // for large problems when the knob is unset)
   static int forced = -1, group_m = 8;
   if (forced < 0) {
     const char* e = getenv("LD_GEMM_TILE"); forced = e ? atoi(e) : 0;
@@ -909,8 +1071,12 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     cfg = (tiles256 >= 512 && p.K >= 1024) ? 3 : 1;     // (the DiT's 1920x1920 GEMMs: 256x256 tiles 0.26 ms vs 0.29 ms on 128x128)
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
-  if (cfg != 3 && cfg != 7 && cfg != 8) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  if (cfg != 3 && cfg != 7 && cfg != 8 && cfg != 11) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  // default for the large linear layers: the register-staged 4-wave loop (qkv / 4h / 4h->h GEMMs 3-6 % faster than the
+  // 8-wave kernel); the gated-residual epilogue on a short K (DiT proj, K = 1920) hides its operand loads better with 8 waves
+  const bool w4r_default = forced == 0 && pp_ok && !conv && !(pick_epilogue(p) == EPI_GATE && p.K < 4096);
   auto big = [&](const GemmParams& q) {
+    if ((cfg == 11 || w4r_default) && pp_ok && !conv) return launch_w4r(q, stream);
     if (cfg == 8 && pp_ok) return launch_w4(q, conv, stream);
     return (cfg == 7 && pp_ok) ? launch_pp(q, conv, stream) : launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);
   };
