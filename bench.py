@@ -166,7 +166,7 @@ def main():
                        "sampler_steps": cfg.sampler.num_steps, "llm_steps": (1244 if not stream else None) if not args.tiny else None,
                        "parallelism": f"dp{world} over prompts, RCCL all_gather of uint8 frames only"},
             "stage_seconds_rank0": {k: round(v / args.steps, 3) for k, v in pipe.timings.items()},
-            "roofline": {"kernel": "ld_attn_pipe2_kernel (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (d.heads, d.seq_len),
+            "roofline": {"kernel": "ld_attn_pipe2_w4_kernel (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (d.heads, d.seq_len),
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          # HBM bytes per launch from rocprofv3 PMC passes at this shape (profiles/r01c_attn_pipe2_pmc_hbm.csv):
