@@ -122,6 +122,25 @@ int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, cons
                    int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit,
                    const void* qkv_fused, const float* cos_t, const float* sin_t, void* stream);
 
+/* One decode step of GPT.sample (landiff/llm/models/transformer.py:91-119 with the cached blocks of
+ * transformer_blocks.py:128-236) for B = 2 (the CFG pair): embedding of *token, n_layers x [RMSNorm+qkv GEMV, RoPE +
+ * KV append + key-split attention at position *pos, wo GEMV + residual, RMSNorm + gated-GELU MLP GEMVs + residual],
+ * final LayerNorm (fp32) and the fp32 head -> logits [B][vocab].  Exactly the launches a caller would issue through
+ * ld_llm_embed / ld_gemv / ld_llm_kv_attn / ld_layernorm_bf16_to_f32, queued from native code in one call: the
+ * ~150 launches of a step are then bound by the GPU (~1.2 ms) and not by the host language's per-call overhead.
+ * All step state (*token, *pos) is read on the device; buffers are caller-owned: x/att [B][hidden], qkv [B][3*hidden],
+ * gate [B][mlp] bf16, attn_ws B*heads*nsplit*130 floats, lnf_out [B][hidden] fp32, logits [B][vocab] fp32. */
+typedef struct ld_llm_layer {
+  const void* wqkv; const void* wo; const void* w1; const void* w3; const void* w2;   /* bf16 [3h][h] [h][h] [mlp][h] [mlp][h] [h][mlp] */
+  const float* n0; const float* n1;                                                    /* RMSNorm gains, fp32 [h] */
+  void* k_cache; void* v_cache;                                                        /* bf16 [B][Lmax][heads][128] */
+} ld_llm_layer;
+int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, const float* emb_table, const int64_t* token,
+                          const int32_t* pos, void* x, void* qkv, void* att, void* gate, float* attn_ws,
+                          const float* cos_t, const float* sin_t, const float* lnf_w, const float* lnf_b, float* lnf_out,
+                          const float* head_w, float* logits, int64_t B, int64_t hidden, int64_t heads, int64_t mlp,
+                          int64_t vocab, int64_t Lmax, int64_t nsplit, float rms_eps, float ln_eps, void* stream);
+
 /* nn.Embedding lookup of *token (fp32 table [V][D]) -> bf16 features [B][D] (landiff/llm/modules/tokenizer.py:10-55). */
 int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B, int64_t D, void* stream);
 

@@ -36,6 +36,12 @@ class Epilogue(Structure):
     ]
 
 
+class LlmLayer(Structure):
+    """Mirror of ld_llm_layer (include/landiff_hip.h): one decoder block's weights and its KV cache."""
+
+    _fields_ = [(n, c_void_p) for n in ("wqkv", "wo", "w1", "w3", "w2", "n0", "n1", "k_cache", "v_cache")]
+
+
 _lib = None
 
 I64 = c_int64
@@ -55,6 +61,8 @@ SIGNATURES: dict[str, list] = {
     "ld_llm_rope_append": [P, P, P, P, P, P, P, I64, I64, I64, I64, P],
     "ld_llm_kv_attn": [P, P, P, P, P, I64, I64, I64, I64, P, I64, P, P, P, P],
     "ld_llm_embed": [P, P, P, I64, I64, P],
+    "ld_llm_decode_forward": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
+                              c_float, c_float, P],
     "ld_llm_logits_to_probs": [P, P, P, I64, I32, c_float, c_float, P, P, I64, I32, c_float, P],
     "ld_llm_decode_advance": [P, P, P, P, P, P, P],
     "ld_layernorm": [P, I64, I32, P, P, P, I64, I32, I64, I64, c_float, P, I64, I64, I64, I64, I64, I64, I64, P],

@@ -247,6 +247,168 @@ __global__ __launch_bounds__(256) void ld_gemv_kernel(GemvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Register-resident GEMV for bf16 x / bf16 W (the LLM decode shapes).  One workgroup = R consecutive output rows; its
+// 256 threads split K (thread t owns the 16-byte chunks t, t+256, ...: J of them), so every load instruction of the
+// workgroup covers 4 KB of one weight row.  There is no loop: each thread issues its x chunks, then ALL of its R*J
+// (x2 when gated) weight loads, and only then starts on the RMSNorm -- the whole matrix is in flight across the
+// resident workgroups from the first microsecond, which is what a 5-25 us kernel needs to get near the HBM rate
+// (tools/probe/hbm_probe.hip: 5.0 / 5.9 / 6.4 TB/s for 25 / 45 / 90 MB reads at this launch granularity).
+// Dot products use v_dot2_f32_bf16 on the packed operands (bf16 products are exact in fp32); the R*B (x2) partial
+// sums are reduced across the wave with a transposing butterfly (V + 6 - log2 V shuffles for V values instead of
+// 6 V) and across the 4 waves through LDS.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
+// Sum V (power of two, <= 64) per-lane values over the 64 lanes; afterwards lane L holds the total of value
+// L >> (6 - log2 V) (every lane of that group holds the same number).
+template <int V, int N = V, int O = 32>
+__device__ __forceinline__ void wave_sum_multi(float (&v)[V], int lane) {
+  if constexpr (N > 1) {
+    const bool up = (lane & O) != 0;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      const float keep = up ? v[i + N / 2] : v[i];
+      const float send = up ? v[i] : v[i + N / 2];
+      v[i] = keep + __shfl_xor(send, O, 64);
+    }
+    wave_sum_multi<V, N / 2, O / 2>(v, lane);
+  } else if constexpr (O > 0) {
+    v[0] += __shfl_xor(v[0], O, 64);
+    wave_sum_multi<V, 1, O / 2>(v, lane);
+  }
+}
+constexpr int ceil_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+constexpr int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+template <int B, int R, int J, bool GATED, bool NORM>
+__global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbatch) {
+  constexpr int NV = R * B * (GATED ? 2 : 1), V = ceil_pow2(NV), LOGV = ilog2(V);
+  __shared__ float red[2][4][V];
+  __shared__ float ssq[4][B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunk = p.K >> 3;
+  const int er = tid / B, eb = tid - er * B;          // this thread's epilogue output within a batch: (row er, batch row eb)
+
+  u32x4_t wn[R][J], w2n[GATED ? R : 1][J];
+  float e_bias_n = 0.f, e_res_n = 0.f;
+  // request one batch (R consecutive weight rows + the epilogue operands of its outputs)
+  auto request = [&](int batch) {
+    const int n0 = batch * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long row = (n0 + r < p.N) ? n0 + r : p.N - 1;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int c = j * 256 + tid;
+        wn[r][j] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (c < nchunk) wn[r][j] = __builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)p.W + row * p.K + c * 8));
+        if (GATED) {
+          w2n[r][j] = (u32x4_t){0u, 0u, 0u, 0u};
+          if (c < nchunk) w2n[r][j] = __builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)p.W2 + row * p.K + c * 8));
+        }
+      }
+    }
+    const int en = n0 + er;
+    if (tid < R * B && en < p.N) {
+      if (p.bias) e_bias_n = bf2f(p.bias[en]);
+      if (p.resid) e_res_n = p.out_f32 ? ((const float*)p.resid)[eb * p.ldr + en] : bf2f(((const bf16_t*)p.resid)[eb * p.ldr + en]);
+    }
+  };
+
+  // ---- x (L2) and the RMSNorm gains first, then the first batch of weight rows (HBM): all in flight together ----
+  u32x4_t xq[B][J];
+  f32x4_t g0[NORM ? J : 1], g1[NORM ? J : 1];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = j * 256 + tid;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      xq[b][j] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (c < nchunk) xq[b][j] = *(const u32x4_t*)((const bf16_t*)p.x + b * p.ldx + c * 8);
+    }
+    if (NORM && c < nchunk) { g0[j] = *(const f32x4_t*)(p.norm_w + c * 8); g1[j] = *(const f32x4_t*)(p.norm_w + c * 8 + 4); }
+  }
+  int batch = blockIdx.x;
+  request(batch);
+
+  // ---- x: optional fused RMSNorm (transformer_blocks.py:22-40), back to packed bf16 ----
+  if (NORM) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float lo = bf_lo(xq[b][j][e]), hi = bf_hi(xq[b][j][e]); ss += lo * lo + hi * hi; }
+      ss = wave_sum(ss);
+      if (lane == 0) ssq[wave][b] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const float r1 = rsqrtf((ssq[0][b] + ssq[1][b] + ssq[2][b] + ssq[3][b]) / (float)p.K + p.norm_eps);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if (j * 256 + tid < nchunk) {
+          const u32x4_t a = xq[b][j];
+          xq[b][j] = (u32x4_t){pack_bf16x2(bf_lo(a[0]) * r1 * g0[j][0], bf_hi(a[0]) * r1 * g0[j][1]),
+                               pack_bf16x2(bf_lo(a[1]) * r1 * g0[j][2], bf_hi(a[1]) * r1 * g0[j][3]),
+                               pack_bf16x2(bf_lo(a[2]) * r1 * g1[j][0], bf_hi(a[2]) * r1 * g1[j][1]),
+                               pack_bf16x2(bf_lo(a[3]) * r1 * g1[j][2], bf_hi(a[3]) * r1 * g1[j][3])};
+        }
+      }
+    }
+  }
+
+  // ---- batches batch, batch + gridDim.x, ...: the next batch's rows are requested before this one is consumed ----
+  int par = 0;
+#pragma unroll 1
+  for (; batch < nbatch; batch += gridDim.x, par ^= 1) {
+    u32x4_t w[R][J], w2[GATED ? R : 1][J];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < J; ++j) { w[r][j] = wn[r][j]; if (GATED) w2[r][j] = w2n[r][j]; }
+    const float e_bias = e_bias_n, e_res = e_res_n;
+    if (batch + (int)gridDim.x < nbatch) request(batch + gridDim.x);
+
+    float v[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[r * B + b] = dot2_bf16(w[r][j][e], xq[b][j][e], v[r * B + b]);
+            if (GATED) v[R * B + r * B + b] = dot2_bf16(w2[r][j][e], xq[b][j][e], v[R * B + r * B + b]);
+          }
+    wave_sum_multi<V>(v, lane);
+    if ((lane & ((64 >> LOGV) - 1)) == 0) red[par][wave][lane >> (6 - LOGV)] = v[0];
+    __syncthreads();
+    const int en = batch * R + er;
+    if (tid < R * B && en < p.N) {
+      const float(&rd)[4][V] = red[par];
+      float a = rd[0][tid] + rd[1][tid] + rd[2][tid] + rd[3][tid];
+      if (p.bias) a += e_bias;
+      a = rbf(a);                                        // bf16 Linear output
+      if (p.act) a = rbf(apply_act(p.act, a));
+      if (GATED) a = rbf(a * rbf(rd[0][R * B + tid] + rd[1][R * B + tid] + rd[2][R * B + tid] + rd[3][R * B + tid]));
+      if (p.resid) a = p.out_f32 ? e_res + a : rbf(e_res + a);
+      if (p.out_f32) ((float*)p.out)[eb * p.ldo + en] = a;
+      else ((bf16_t*)p.out)[eb * p.ldo + en] = f2bf(a);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // RMSNorm / LayerNorm over short rows (fp32 math), one wave per row.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ld_rmsnorm_kernel(const bf16_t* x, const float* w, bf16_t* out,
@@ -291,6 +453,52 @@ __global__ __launch_bounds__(256) void ld_ln_f32out_kernel(const bf16_t* x, long
   ss = wave_sum(ss);
   const float rs = rsqrtf(ss / (float)D + eps);
   for (int i = lane; i < D; i += 64) out[(long)r * D + i] = (bf2f(xr[i]) - mean) * rs * w[i] + b[i];
+}
+
+// Same, for rows of at most 4096 elements (D % 8 == 0): the row is read once with 16-byte loads and stays in registers
+// for the mean, the centred second moment and the affine output (the three-pass kernel above spent 22 us on the two
+// rows of a decode step, all of it dependent 2-byte loads).
+__global__ __launch_bounds__(256) void ld_ln_f32out_reg_kernel(const bf16_t* x, long ldx, const float* w, const float* b,
+                                                               float* out, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const bf16_t* xr = x + (long)r * ldx;
+  const int nchunk = D >> 3;
+  float v[8][8];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = lane + 64 * k;
+    u32x4_t a = (u32x4_t){0u, 0u, 0u, 0u};
+    if (c < nchunk) a = *(const u32x4_t*)(xr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[k][2 * e] = bf_lo(a[e]); v[k][2 * e + 1] = bf_hi(a[e]); s += v[k][2 * e] + v[k][2 * e + 1]; }
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (lane + 64 * k < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; ss += d * d; }
+    }
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)D + eps);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) {
+      const f32x4_t w0 = *(const f32x4_t*)(w + c * 8), w1 = *(const f32x4_t*)(w + c * 8 + 4);
+      const f32x4_t b0 = *(const f32x4_t*)(b + c * 8), b1 = *(const f32x4_t*)(b + c * 8 + 4);
+      f32x4_t o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o0[e] = (v[k][e] - mean) * rs * w0[e] + b0[e]; o1[e] = (v[k][4 + e] - mean) * rs * w1[e] + b1[e]; }
+      *(f32x4_t*)(out + (long)r * D + c * 8) = o0;
+      *(f32x4_t*)(out + (long)r * D + c * 8 + 4) = o1;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,38 +626,24 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
     if (tid == 0) { out_ws[0] = -3.0e38f; out_ws[1] = 0.f; }
     return;
   }
+  // Request order = dependency order: the new token's q/k/v + rotation factors first (short, L2), then this wave's K
+  // rows AND V rows (4 keys per trip, <= KV_MAXIT trips) all at once -- one exposed HBM latency per launch, and the RoPE
+  // arithmetic runs underneath it.  The key being appended this step is taken from qkv directly (its cache slot is
+  // written for later steps but not read back here), so the prologue needs no barrier.
   float qreg[8];
+  u32x4_t a_q = (u32x4_t){0u, 0u, 0u, 0u}, a_k = a_q, a_v = a_q;
+  float cs[4], sn[4];
+  const int pos = L - 1;
   if (qkv) {
-    const int pos = L - 1;
     const bf16_t* src = qkv + ((long)b * 3 * H + h) * D;      // [B][3][H][128]: q at +0, k at +H*D, v at +2*H*D
-    if (pos >= k_begin && pos < k_end && tid < 64) {          // this workgroup owns the new key: append it (one wave)
-      const float c = cos_t[pos * 64 + tid], sn = sin_t[pos * 64 + tid];
-      const float ka = bf2f(src[(long)H * D + 2 * tid]), kb = bf2f(src[(long)H * D + 2 * tid + 1]);
-      const long co = (((long)b * Lmax + pos) * H + h) * D + 2 * tid;
-      kc[co] = f2bf(ka * c - kb * sn);
-      kc[co + 1] = f2bf(ka * sn + kb * c);
-      vc[co] = src[2L * H * D + 2 * tid];
-      vc[co + 1] = src[2L * H * D + 2 * tid + 1];
-    }
-    const u32x4_t a = *(const u32x4_t*)(src + sub * 8);
+    a_q = *(const u32x4_t*)(src + sub * 8);
+    a_k = *(const u32x4_t*)(src + (long)H * D + sub * 8);
+    a_v = *(const u32x4_t*)(src + 2L * H * D + sub * 8);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float c = cos_t[pos * 64 + sub * 4 + e], sn = sin_t[pos * 64 + sub * 4 + e];
-      const float qa = bf_lo(a[e]), qb = bf_hi(a[e]);
-      qreg[2 * e] = rbf(qa * c - qb * sn);
-      qreg[2 * e + 1] = rbf(qa * sn + qb * c);
-    }
-    __syncthreads();                                           // the appended k/v row is read below by this workgroup
+    for (int e = 0; e < 4; ++e) { cs[e] = cos_t[pos * 64 + sub * 4 + e]; sn[e] = sin_t[pos * 64 + sub * 4 + e]; }
   } else {
-    const bf16_t* qv = q + ((long)b * H + h) * D;
-    const u32x4_t a = *(const u32x4_t*)(qv + sub * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { qreg[2 * e] = bf_lo(a[e]); qreg[2 * e + 1] = bf_hi(a[e]); }
+    a_q = *(const u32x4_t*)(q + ((long)b * H + h) * D + sub * 8);
   }
-  const float inv_sqrt_d = 0.08838834764831845f;
-  // Memory-level parallelism: a wave's K rows AND V rows (4 keys per trip, <= KV_MAXIT trips) are all requested before
-  // anything is computed -- one exposed memory latency per launch instead of one per trip (the trip-at-a-time loop this
-  // replaces spent ~10 us per launch waiting on ~20 dependent round trips).
   u32x4_t kr[KV_MAXIT], vr[KV_MAXIT];
 #pragma unroll
   for (int it = 0; it < KV_MAXIT; ++it) {
@@ -461,6 +655,33 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
       vr[it] = __builtin_nontemporal_load((const u32x4_t*)(vc + off));
     }
   }
+  if (qkv) {
+    u32x4_t knew;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float qa = bf_lo(a_q[e]), qb = bf_hi(a_q[e]);
+      qreg[2 * e] = rbf(qa * cs[e] - qb * sn[e]);
+      qreg[2 * e + 1] = rbf(qa * sn[e] + qb * cs[e]);
+      const float ka = bf_lo(a_k[e]), kb = bf_hi(a_k[e]);
+      knew[e] = pack_bf16x2(ka * cs[e] - kb * sn[e], ka * sn[e] + kb * cs[e]);
+    }
+    const int pk = pos - k_begin;                              // slot of the new key inside this split, if it is here
+    if (pk >= 0 && pk < n) {
+      if (wave == 0 && kq == 0) {                              // append for the following steps
+        const long co = (((long)b * Lmax + pos) * H + h) * D + sub * 8;
+        *(u32x4_t*)(kc + co) = knew;
+        *(u32x4_t*)(vc + co) = a_v;
+      }
+#pragma unroll
+      for (int it = 0; it < KV_MAXIT; ++it) {
+        if (wave * 4 + it * 16 + kq == pk) { kr[it] = knew; vr[it] = a_v; }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { qreg[2 * e] = bf_lo(a_q[e]); qreg[2 * e + 1] = bf_hi(a_q[e]); }
+  }
+  const float inv_sqrt_d = 0.08838834764831845f;
   float lmax = -3.0e38f;
   float sreg[KV_MAXIT];
 #pragma unroll
@@ -656,8 +877,49 @@ int launch_gemv_cfg(const GemvParams& p, hipStream_t st) {
   return ld_check_launch("ld_gemv");
 }
 
+template <int B, int R, int J, bool GATED, bool NORM>
+int launch_gemv_reg(const GemvParams& p, hipStream_t st) {
+  // nbatch batches of R rows over at most `cap` workgroups, every workgroup taking the same number of batches
+  static const int cap = getenv("LD_GEMV_WGS") ? atoi(getenv("LD_GEMV_WGS")) : 768;
+  const int nbatch = (p.N + R - 1) / R;
+  const int trips = (nbatch + cap - 1) / cap;
+  const int grid = (nbatch + trips - 1) / trips;
+  hipLaunchKernelGGL((ld_gemv_reg_kernel<B, R, J, GATED, NORM>), dim3((unsigned)grid), dim3(256), 0, st, p, nbatch);
+  return ld_check_launch("ld_gemv");
+}
+
+// R rows per batch: R*J (x2 gated) 16-byte loads per thread in flight per batch, two batches deep.
+template <int B, int J, bool GATED, bool NORM>
+int launch_gemv_reg_r(const GemvParams& p, int R, hipStream_t st) {
+  constexpr int L1 = J * (GATED ? 2 : 1);            // loads per thread per row
+  if constexpr (L1 <= 2 && B <= 2) { if (R >= 8) return launch_gemv_reg<B, 8, J, GATED, NORM>(p, st); }
+  if constexpr (L1 <= 4) { if (R >= 4) return launch_gemv_reg<B, 4, J, GATED, NORM>(p, st); }
+  if (R >= 2) return launch_gemv_reg<B, 2, J, GATED, NORM>(p, st);
+  return launch_gemv_reg<B, 1, J, GATED, NORM>(p, st);
+}
+
+template <int B, int J>
+int launch_gemv_reg_j(const GemvParams& p, int R, hipStream_t st) {
+  const bool gated = p.W2 != nullptr, norm = p.norm_w != nullptr;
+  if constexpr (J <= 2) {
+    if (gated) return norm ? launch_gemv_reg_r<B, J, true, true>(p, R, st) : launch_gemv_reg_r<B, J, true, false>(p, R, st);
+  }
+  return norm ? launch_gemv_reg_r<B, J, false, true>(p, R, st) : launch_gemv_reg_r<B, J, false, false>(p, R, st);
+}
+
 template <int B>
 int launch_gemv_b(const GemvParams& p, hipStream_t st) {
+  static const int mode = getenv("LD_GEMV_MODE") ? atoi(getenv("LD_GEMV_MODE")) : 0;     // 1 = streaming-loop kernel only
+  static const int forced_r = getenv("LD_GEMV_R") ? atoi(getenv("LD_GEMV_R")) : 0;
+  const int nchunk = p.K >> 3;
+  const bool gated = p.W2 != nullptr;
+  if (mode != 1 && !p.w_f32 && !p.x_f32 && !p.in_act) {
+    if (nchunk <= 256) return launch_gemv_reg_j<B, 1>(p, forced_r ? forced_r : 4, st);     // measured: tools/gemv_shapes.py
+    if (nchunk <= 512) return launch_gemv_reg_j<B, 2>(p, forced_r ? forced_r : (gated ? 2 : 4), st);
+    if constexpr (B <= 2) {
+      if (nchunk <= 1536 && !gated) return launch_gemv_reg_j<B, 6>(p, forced_r ? forced_r : 2, st);
+    }
+  }
   if (p.w_f32) return launch_gemv_cfg<B, true, 1>(p, st);
   if (p.W2 || p.N < 4096) return launch_gemv_cfg<B, false, 1>(p, st);   // gated MLP, or few rows: keep all 256 CUs busy
   return launch_gemv_cfg<B, false, 2>(p, st);     // (one row per wave measured slower at N = 6144: 12.4 vs 11.5 us)
@@ -700,8 +962,12 @@ LD_API int ld_rmsnorm_bf16(const void* x, const float* w, void* out, int64_t row
 LD_API int ld_layernorm_bf16_to_f32(const void* x, int64_t ldx, const float* w, const float* b, float* out,
                                     int64_t rows, int64_t D, float eps, void* stream) {
   LD_REQUIRE(x && w && b && out, "ld_layernorm_bf16_to_f32: null pointer");
-  hipLaunchKernelGGL(ld_ln_f32out_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, (long)ldx, w, b, out, (int)rows, (int)D, eps);
+  if (D % 8 == 0 && D <= 4096 && ldx % 8 == 0)
+    hipLaunchKernelGGL(ld_ln_f32out_reg_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (long)ldx, w, b, out, (int)rows, (int)D, eps);
+  else
+    hipLaunchKernelGGL(ld_ln_f32out_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (long)ldx, w, b, out, (int)rows, (int)D, eps);
   return ld_check_launch("ld_layernorm_bf16_to_f32");
 }
 
@@ -754,6 +1020,40 @@ LD_API int ld_llm_embed(const float* table, const int64_t* token, void* out, int
   hipLaunchKernelGGL(ld_embed_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      table, (const long*)token, (bf16_t*)out, (int)B, (int)D);
   return ld_check_launch("ld_llm_embed");
+}
+
+LD_API int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, const float* emb_table, const int64_t* token,
+                                 const int32_t* pos, void* x, void* qkv, void* att, void* gate, float* attn_ws,
+                                 const float* cos_t, const float* sin_t, const float* lnf_w, const float* lnf_b,
+                                 float* lnf_out, const float* head_w, float* logits, int64_t B, int64_t hidden,
+                                 int64_t heads, int64_t mlp, int64_t vocab, int64_t Lmax, int64_t nsplit, float rms_eps,
+                                 float ln_eps, void* stream) {
+  LD_REQUIRE(layers && n_layers > 0 && emb_table && token && pos && x && qkv && att && gate && attn_ws && cos_t && sin_t &&
+             lnf_w && lnf_b && lnf_out && head_w && logits, "ld_llm_decode_forward: null pointer");
+  LD_REQUIRE(hidden == heads * 128, "ld_llm_decode_forward: head_dim must be 128 (hidden=%ld heads=%ld)", (long)hidden, (long)heads);
+  LD_REQUIRE(nsplit > 1, "ld_llm_decode_forward: the decode path is the key-split attention (nsplit > 1)");
+  int rc = ld_llm_embed(emb_table, token, x, B, hidden, stream);
+  for (int64_t i = 0; i < n_layers && rc == 0; ++i) {
+    const ld_llm_layer& w = layers[i];
+    LD_REQUIRE(w.wqkv && w.wo && w.w1 && w.w3 && w.w2 && w.n0 && w.n1 && w.k_cache && w.v_cache,
+               "ld_llm_decode_forward: layer %ld has a null pointer", (long)i);
+    rc = ld_gemv(x, hidden, 0, w.wqkv, nullptr, 0, nullptr, nullptr, 0, qkv, 3 * hidden, 0, B, 3 * hidden, hidden, 0, 0,
+                 w.n0, rms_eps, stream);
+    if (rc) break;
+    rc = ld_llm_kv_attn(nullptr, w.k_cache, w.v_cache, pos, att, B, 1, heads, Lmax, attn_ws, nsplit, qkv, cos_t, sin_t, stream);
+    if (rc) break;
+    rc = ld_gemv(att, hidden, 0, w.wo, nullptr, 0, nullptr, x, hidden, x, hidden, 0, B, hidden, hidden, 0, 0, nullptr, 0.f, stream);
+    if (rc) break;
+    rc = ld_gemv(x, hidden, 0, w.w1, w.w3, 0, nullptr, nullptr, 0, gate, mlp, 0, B, mlp, hidden, 0, LD_ACT_GELU_TANH,
+                 w.n1, rms_eps, stream);
+    if (rc) break;
+    rc = ld_gemv(gate, mlp, 0, w.w2, nullptr, 0, nullptr, x, hidden, x, hidden, 0, B, hidden, mlp, 0, 0, nullptr, 0.f, stream);
+  }
+  if (rc) return rc;
+  rc = ld_layernorm_bf16_to_f32(x, hidden, lnf_w, lnf_b, lnf_out, B, hidden, ln_eps, stream);
+  if (rc) return rc;
+  return ld_gemv(lnf_out, hidden, 1, head_w, nullptr, 1, nullptr, nullptr, 0, logits, vocab, 1, B, vocab, hidden, 0, 0,
+                 nullptr, 0.f, stream);
 }
 
 LD_API int ld_llm_logits_to_probs(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided,

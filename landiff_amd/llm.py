@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import math
 
+import time
+
 import torch
 
 from . import ops
@@ -119,6 +121,7 @@ class LLMRunner:
         self.top_k, self.top_p = None, None
         self.attn_ws = e(B * H * self.nsplit * 130, dt=torch.float32)
         self._graph = None
+        self._layer_table = None
 
     # ---- conditioning ------------------------------------------------------------------------
     def _micro_cond(self, frames: float, motion_score: float):
@@ -179,7 +182,19 @@ class LLMRunner:
         ops.gemv(self.lnf, self.head, self.logits)
 
     def _decode_forward(self):
-        """One token: embedding of *token at position *pos -> logits [2, V] (all sizes static: graph-capturable)."""
+        """One token: embedding of *token at position *pos -> logits [2, V].  All sizes are static and every per-step scalar
+        lives on the device; the ~150 launches are queued by ONE native call (ld_llm_decode_forward) -- issued one by one
+        from Python the step was bound by the interpreter (1.3 ms of host time per step), and replaying it as a HIP graph
+        costs 1.2 ms of host time per launch of the 164-node graph."""
+        c = self.cfg
+        if self._layer_table is None:
+            self._layer_table = ops.llm_layer_table(self.blocks, self.kc, self.vc)
+        ops.llm_decode_forward(self._layer_table, self.emb, self.token, self.pos, self.x, self.qkv, self.att, self.gate,
+                               self.attn_ws, self.cos, self.sin, self.ln_w, self.ln_b, self.lnf, self.head, self.logits,
+                               c.heads, self.Lmax, self.nsplit, c.rms_eps, c.ln_eps)
+
+    def _decode_forward_per_op(self):
+        """The same step issued op by op through the C-ABI (kept for tests: must equal _decode_forward bit for bit)."""
         c, B = self.cfg, self.B
         ops.llm_embed(self.emb, self.token, self.x)
         for i, w in enumerate(self.blocks):      # 6 launches per layer: RMSNorm rides in the GEMVs, RoPE/append in attention
@@ -201,7 +216,7 @@ class LLMRunner:
     # ---- decode loop -----------------------------------------------------------------------------
     @torch.no_grad()
     def sample(self, text_emb: torch.Tensor, *, motion_score: float = 0.1, num_frames: int = 13, guidance_scale: float = 7.5,
-               temperature: float = 1.0, seed: int | None = None, generator=None, use_graph: bool = True,
+               temperature: float = 1.0, seed: int | None = None, generator=None, use_graph: bool = False,
                teacher_fed=None, logits_log=None, top_k: int | None = None, top_p: float | None = None) -> torch.Tensor:
         """Returns the clamped visual token ids, int64 [n_visual] on the device (lm_model.py:509-516).
         top_k / top_p filter the unrestricted positions inside the sampling kernel (lm_model.py:441-447)."""
@@ -236,6 +251,7 @@ class LLMRunner:
         graph = None
         if use_graph and not debug and steps > 4:
             graph = self._capture(guided, guidance_scale, temperature, generator)
+        t_enq = time.perf_counter()
         for it in range(steps):
             if teacher_fed is not None:
                 self.token.copy_(teacher_fed[it].reshape(1))
@@ -246,6 +262,7 @@ class LLMRunner:
                 self._sample_and_advance(guided, guidance_scale, temperature, generator)
             if logits_log is not None:
                 logits_log.append(self.cfg_logits.clone())
+        self.host_enqueue_s = time.perf_counter() - t_enq      # host time to enqueue the loop (< wall time when the GPU is the bound)
         assert int(self.out_count.item()) == n_visual, (int(self.out_count.item()), n_visual)
         return self.out_tokens[:n_visual].clamp(0, c.visual_vocab - 1)
 

@@ -170,6 +170,33 @@ def llm_embed(table, token, out):
     check(_lib.load().ld_llm_embed(_ptr(table), _ptr(token), _ptr(out), B, D, _stream()), "ld_llm_embed")
 
 
+def llm_layer_table(blocks, k_caches, v_caches):
+    """Host-side array of ld_llm_layer for llm_decode_forward (keeps no references: the caller owns the tensors)."""
+    arr = (_lib.LlmLayer * len(blocks))()
+    for i, w in enumerate(blocks):
+        for name in ("wqkv", "wo", "w1", "w3", "w2"):
+            assert w[name].dtype == torch.bfloat16 and w[name].is_contiguous()
+            setattr(arr[i], name, w[name].data_ptr())
+        for name in ("n0", "n1"):
+            assert w[name].dtype == torch.float32 and w[name].is_contiguous()
+            setattr(arr[i], name, w[name].data_ptr())
+        arr[i].k_cache, arr[i].v_cache = k_caches[i].data_ptr(), v_caches[i].data_ptr()
+    return arr
+
+
+def llm_decode_forward(table, emb, token, pos, x, qkv, att, gate, attn_ws, cos_t, sin_t, lnf_w, lnf_b, lnf_out, head, logits,
+                       heads, Lmax, nsplit, rms_eps, ln_eps):
+    """One decode step (embedding -> all blocks -> final LN -> fp32 head), every launch queued from native code."""
+    B, hidden = x.shape
+    for t in (x, qkv, att, gate, lnf_out, logits, head):
+        assert t.is_contiguous()
+    check(_lib.load().ld_llm_decode_forward(ctypes.addressof(table), len(table), _ptr(emb), _ptr(token), _ptr(pos), _ptr(x),
+                                            _ptr(qkv), _ptr(att), _ptr(gate), _ptr(attn_ws), _ptr(cos_t), _ptr(sin_t),
+                                            _ptr(lnf_w), _ptr(lnf_b), _ptr(lnf_out), _ptr(head), _ptr(logits), B, hidden,
+                                            heads, gate.shape[1], logits.shape[1], Lmax, nsplit, float(rms_eps),
+                                            float(ln_eps), _stream()), "ld_llm_decode_forward")
+
+
 def llm_logits_to_probs(logits, probs, cfg_logits, guided, scale, temperature, pos=None, allowed=None,
                         top_k=None, top_p=None):
     V = probs.shape[-1]

@@ -193,6 +193,29 @@ def test_llm_teacher_forced_logits_and_sampler(cuda, setup):
             assert tok in torch.topk(log3[step][0], 3).indices.cpu().tolist(), (i, tok)
 
 
+def test_llm_native_step_equals_per_op_step(cuda, setup):
+    """ld_llm_decode_forward (the whole step queued by one native call) issues exactly the launches of the per-op path:
+    same tokens from the same seed, eager and graph-replayed, and the same logits bit for bit on one step."""
+    from landiff_amd.llm import LLMRunner
+    cfg, st = setup
+    c = cfg.llm
+    text = torch.randn(5, c.text_dim, generator=torch.Generator().manual_seed(9))
+    run = LLMRunner(st["llm"], c, cuda, max_text=32, max_frames=c.segment_length)
+    outs = []
+    for mode in ("native", "per_op", "graph"):
+        if mode == "per_op":
+            run._decode_forward = run._decode_forward_per_op
+        gen = torch.Generator(device=cuda); gen.manual_seed(21)
+        log = []
+        codes = run.sample(text, num_frames=c.segment_length, guidance_scale=7.5, generator=gen,
+                           use_graph=(mode == "graph"), logits_log=log if mode != "graph" else None)
+        outs.append((codes.cpu(), torch.cat(log, 0).cpu() if log else None))
+        if mode == "per_op":
+            del run._decode_forward
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_end_to_end_tiny(cuda, setup):
     from landiff_amd.pipeline import LanDiffPipeline, synthetic_inputs
     from oracle.pipeline import PipelineOracle

@@ -37,8 +37,8 @@ cfg = LLMConfig()
 sd = init_state(llm_spec(cfg), 1, dtype=BF, device=dev)
 run = LLMRunner(sd, cfg, dev)
 text = torch.randn(64, cfg.text_dim, device=dev)
-for use_graph in (True, False):
+for use_graph in (True, False, True, False):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     toks = run.sample(text, guidance_scale=7.5, seed=42, use_graph=use_graph)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"decode 1244 steps graph={use_graph}: {dt:.3f} s  ({dt/1244*1e3:.3f} ms/step)")
+    print(f"decode 1244 steps graph={use_graph}: {dt:.3f} s  ({dt/1244*1e3:.3f} ms/step), host enqueue {run.host_enqueue_s:.3f} s")
