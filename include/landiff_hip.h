@@ -88,6 +88,20 @@ int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
                      const int32_t* fid_q, const int32_t* fid_k,
                      const int32_t* kt_min, const int32_t* kt_max, void* stream);
 
+/* ---- tokenizer encoder side (ld_tokenize.hip) ---- */
+
+/* VideoVQ.norm_features + the "b t c h w -> b (t h w) c" rearrange in front of TiTokEncoder.patch_embed
+ * (landiff/tokenizer/models/video_titok_vq.py:226-231, landiff/tokenizer/modules/blocks.py:598-600):
+ * features [T][C][P] (fp32 if in_f32 else bf16, P = h*w) -> out [T*P][C] bf16 = bf16((x - mean[c]) / (std[c] + 1e-8)). */
+int ld_feature_norm_cl(const void* features, int32_t in_f32, const float* mean, const float* stdv, void* out,
+                       int64_t T, int64_t C, int64_t P, void* stream);
+
+/* Nearest code of vector-quantize-pytorch's EuclideanCodebook.forward in eval (argmax of -cdist, fp32), called by
+ * VideoVQ.encode_to_index (video_titok_vq.py:196-200): x bf16 [rows][ldx] (first dim columns), codebook fp32 [V][dim]
+ * -> idx int64 [rows] = the first code minimising |x|^2 + |e|^2 - 2 x.e. */
+int ld_vq_nearest(const void* x, int64_t ldx, const float* codebook, int64_t* idx, int64_t rows, int64_t V,
+                  int64_t dim, void* stream);
+
 /* ---- HBM-bound small-batch kernels (ld_llm.hip) ---- */
 
 /* y[b][n] = epi(sum_k in_act(x[b][k]) * W[n][k]), 1 <= B <= 4, weights streamed once (one wave per row).

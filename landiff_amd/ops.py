@@ -106,17 +106,25 @@ def conv_cl(x_padded: torch.Tensor, w: torch.Tensor, T: int, H: int, W: int,
 
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, Nq: int, Nk: int,
-             scale: float, fid_q=None, fid_k=None, kt_min=None, kt_max=None) -> torch.Tensor:
-    """q,k [B,H,Npad,64]; vt [B,H,64,Npad]; out [B,N,H*64] (bf16).  Optional frame mask arrays (int32)."""
+             scale: float, fid_q=None, fid_k=None, kt_min=None, kt_max=None, q_row0: int = 0) -> torch.Tensor:
+    """q,k [B,H,Npad,64]; vt [B,H,64,Npad]; out [B,N,H*64] (bf16).  Optional frame mask arrays (int32).
+    q_row0: the Nq query rows start at row q_row0 of q / fid_q / out (pointer offsets only; Npad must cover
+    q_row0 + Nq rounded up to 128)."""
     _bf16(q, "q"); _bf16(k, "k"); _bf16(vt, "vt"); _bf16(out, "out")
     B, H, Npad, D = q.shape
     assert D == 64 and k.shape == q.shape and tuple(vt.shape) == (B, H, 64, Npad)
     assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous() and out.stride(-1) == 1
     assert out.shape[0] == B and out.shape[2] == H * 64
     lib = _lib.load()
-    check(lib.ld_attn_fwd_bf16(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), B, H, Nq, Nk, Npad,
+    qp, op, fqp = _ptr(q), _ptr(out), _ptr(fid_q)
+    if q_row0:
+        assert B == 1 and q_row0 % 2 == 0 and q_row0 + (Nq + 127) // 128 * 128 <= Npad
+        qp = ctypes.c_void_p(qp.value + q_row0 * 64 * 2)
+        op = ctypes.c_void_p(op.value + q_row0 * out.stride(1) * 2)
+        fqp = ctypes.c_void_p(fqp.value + q_row0 * 4) if fqp is not None else None
+    check(lib.ld_attn_fwd_bf16(qp, _ptr(k), _ptr(vt), op, B, H, Nq, Nk, Npad,
                                out.stride(0), out.stride(1), float(scale),
-                               _ptr(fid_q), _ptr(fid_k), _ptr(kt_min), _ptr(kt_max), _stream()),
+                               fqp, _ptr(fid_k), _ptr(kt_min), _ptr(kt_max), _stream()),
           "ld_attn_fwd_bf16")
     return out
 
@@ -225,6 +233,23 @@ def layernorm(x, w, b, out, eps, *, mod=None, mod_bstride=0, shift_img=0, scale_
                                    mod_bstride, shift_img, scale_img, shift_txt, scale_txt, rows_per_batch, text_len,
                                    _stream()), "ld_layernorm")
     return out
+
+
+def feature_norm_cl(features, mean, std, out, T, C, P):
+    """features [T,C,h,w] (fp32/bf16) -> out [T*P, C] bf16 = (x - mean[c]) / (std[c] + 1e-8)."""
+    assert features.is_contiguous() and out.is_contiguous() and out.dtype == torch.bfloat16
+    assert features.dtype in (torch.float32, torch.bfloat16) and mean.dtype == torch.float32 and std.dtype == torch.float32
+    check(_lib.load().ld_feature_norm_cl(_ptr(features), int(features.dtype == torch.float32), _ptr(mean), _ptr(std), _ptr(out),
+                                         T, C, P, _stream()), "ld_feature_norm_cl")
+
+
+def vq_nearest(x, codebook, idx, dim):
+    """x bf16 [rows, >=dim], codebook fp32 [V, dim] -> idx int64 [rows] (first code at minimum Euclidean distance)."""
+    _bf16(x, "x")
+    assert codebook.dtype == torch.float32 and codebook.is_contiguous() and codebook.shape[1] == dim
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and x.stride(1) == 1
+    check(_lib.load().ld_vq_nearest(_ptr(x), x.stride(0), _ptr(codebook), _ptr(idx), x.shape[0], codebook.shape[0], dim,
+                                    _stream()), "ld_vq_nearest")
 
 
 def qkv_split(qkv, q, k, vt, B, N, H, Npad, *, ln=None, rope=None, eps=1e-6):

@@ -66,6 +66,30 @@ def tokenizer_spec(c: TokenizerConfig) -> Spec:
     return s
 
 
+def tokenizer_encoder_spec(c: TokenizerConfig) -> Spec:
+    """Encoder half of VideoVQ: TiTokEncoder (landiff/tokenizer/modules/blocks.py:311-656, patch_size 1,
+    inside_latent_tokens, bias=False attention) + the feature normalisation buffers (video_titok_vq.py:55-68) +
+    VectorQuantize.project_in / codebook (vector-quantize-pytorch 1.19.2)."""
+    w, cin = c.width, c.out_channels
+    s = [("mean", (cin,), "b"), ("std", (cin,), "g"),
+         ("encoder.patch_embed.weight", (w, cin, 1, 1), "w"), ("encoder.patch_embed.bias", (w,), "b"),
+         ("encoder.IFrame_latent_tokens", (c.iframe_tokens, w), "e"), ("encoder.PFrame_latent_tokens", (c.pframe_tokens, w), "e"),
+         ("encoder.ln_pre.weight", (w,), "g"), ("encoder.ln_pre.bias", (w,), "b")]
+    for i in range(c.layers):
+        p = f"encoder.transformer.{i}."
+        s += [(p + "ln_1.weight", (w,), "g"), (p + "ln_1.bias", (w,), "b"),
+              (p + "attn.wq.weight", (w, w), "w"), (p + "attn.wk.weight", (w, w), "w"),
+              (p + "attn.wv.weight", (w, w), "w"), (p + "attn.wo.weight", (w, w), "w"),
+              (p + "ln_2.weight", (w,), "g"), (p + "ln_2.bias", (w,), "b"),
+              (p + "mlp.c_fc.weight", (4 * w, w), "w"), (p + "mlp.c_fc.bias", (4 * w,), "b"),
+              (p + "mlp.c_proj.weight", (w, 4 * w), "w"), (p + "mlp.c_proj.bias", (w,), "b")]
+    s += [("encoder.ln_post.weight", (w,), "g"), ("encoder.ln_post.bias", (w,), "b"),
+          ("encoder.proj_out.weight", (c.token_size, w), "w"), ("encoder.proj_out.bias", (c.token_size,), "b"),
+          ("quantizer.project_in.weight", (c.codebook_dim, c.token_size), "w"), ("quantizer.project_in.bias", (c.codebook_dim,), "b"),
+          ("quantizer._codebook.embed", (1, c.codebook_size, c.codebook_dim), "e1")]
+    return s
+
+
 def _res2d(p: str, cin: int, cout: int) -> Spec:
     s = [(p + "norm1.weight", (cin,), "g"), (p + "norm1.bias", (cin,), "b"),
          (p + "conv1.weight", (cout, cin, 3, 3), "w"), (p + "conv1.bias", (cout,), "b"),

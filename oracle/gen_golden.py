@@ -310,6 +310,70 @@ def gen_titok():
     save("titok_fp32", z=z, out=out, seed=np.array(6))
 
 
+def gen_titok_encoder():
+    """Encoder half: TiTokEncoder.forward on a tiny config + VideoEncoderMask (tiny dense through the
+    reference's scalar _mask_fn; full size through its vectorised vmap_fn, hashed)."""
+    import torch.nn.attention.flex_attention as fa
+    from landiff.modules.pos_emb import Rope3DPosEmb
+    from landiff.tokenizer.modules.blocks import AttentionImp, AttentionMaskType, PositionalEmbedingType, TiTokEncoder
+    from landiff.tokenizer.modules import flex_attention_mask as fam
+    from landiff_amd.config import TokenizerConfig
+    from landiff_amd.weights import init_state, tokenizer_encoder_spec
+
+    orig_create_mask = fa.create_mask
+    def create_mask_cpu(fn, B, H, Q_LEN, KV_LEN, device="cpu", **kw):
+        return orig_create_mask(lambda b, h, q, k: fn(b, h, q, k), B, H, Q_LEN, KV_LEN, device="cpu")
+    fa.create_mask = create_mask_cpu
+    fam.flex_attention_mod.create_mask = create_mask_cpu
+
+    cfg = TokenizerConfig.tiny()
+    rope = Rope3DPosEmb(dim=cfg.head_dim, max_time=100, max_height=30, max_width=45, one_dim_max_time=100000,
+                        multiple=16, device="cpu")
+    enc = TiTokEncoder(image_size=(cfg.grid_h, cfg.grid_w), image_channels=cfg.out_channels, patch_size=1,
+                       model_size="base", num_latent_tokens=cfg.num_latent_tokens, token_size=cfg.token_size,
+                       width=cfg.width, num_layers=cfg.layers, num_heads=cfg.heads, use_checkpoint=False, qk_norm=False,
+                       causal=False, bias=False, use_cls_token=False, rope_layer=rope,
+                       positional_embedding_type=PositionalEmbedingType.ROPE_3D, attention_imp=AttentionImp.TORCH,
+                       attention_mask_type=AttentionMaskType.VIDEO_ENCODER_MASK, temporal_size=cfg.temporal,
+                       PFrame_tokens=cfg.pframe_tokens, inside_latent_tokens=True)
+    sd = init_state(tokenizer_encoder_spec(cfg), seed=8)
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    enc.load_state_dict(enc_sd, strict=True)
+    enc.eval()
+    torch.manual_seed(4)
+    x = torch.randn(1, cfg.temporal, cfg.out_channels, cfg.grid_h, cfg.grid_w)
+    x = x + 2.0 * torch.randn(1, cfg.temporal, cfg.out_channels, 1, 1)           # frame-dependent content
+    with torch.no_grad():
+        out = enc(x, forward_T=cfg.temporal)                                       # [1, token_size, 1, L]
+    save("titok_enc_fp32", x=x, out=out, seed=np.array(8))
+
+    def make_mask_obj(T, tpf, nI, nP):
+        m = object.__new__(fam.VideoEncoderMask)
+        m.num_frames, m.tokens_per_frame, m.IFrame_tokens, m.PFrame_tokens = T, tpf, nI, nP
+        m.seq_len = T * tpf + nI + nP * (T - 1)
+        m.block_size, m.device = 128, torch.device("cpu")
+        return m
+
+    m = make_mask_obj(4, 6, 5, 3)
+    n = m.seq_len
+    dense = np.zeros((n, n), dtype=bool)
+    for qi in range(n):
+        for ki in range(n):
+            dense[qi, ki] = bool(m._mask_fn(1, 1, qi, ki))
+    mf = make_mask_obj(13, 1350, 330, 74)
+    L = mf.seq_len
+    qi = torch.arange(L)[:, None]
+    ki = torch.arange(L)[None, :]
+    h = hashlib.sha256()
+    rows = np.zeros(L, dtype=np.int64)
+    for r0 in range(0, L, 128):
+        blk = mf.vmap_fn(None, None, qi[r0:r0 + 128], ki).numpy().astype(np.uint8)
+        h.update(np.packbits(blk, axis=None).tobytes())
+        rows[r0:r0 + blk.shape[0]] = blk.sum(1)
+    save("encoder_mask", tiny_dense=dense, tiny_cfg=np.array([4, 6, 5, 3]), full_cfg=np.array([13, 1350, 330, 74]),
+         full_sha256=np.frombuffer(h.digest(), dtype=np.uint8), full_row_counts=rows)
+
+
 def gen_upsampler():
     from landiff.diffusion.semantic_models.modules.vq_gan_blocks import Decoder
     from landiff_amd.config import UpsamplerConfig
@@ -455,7 +519,7 @@ def gen_dit():
 # ------------------------------------------------------------------------------------------
 def main():
     install_stubs()
-    which = sys.argv[1:] or ["schedule", "rope", "llm", "titok", "ups", "vae", "dit"]
+    which = sys.argv[1:] or ["schedule", "rope", "llm", "titok", "titok_enc", "ups", "vae", "dit"]
     if "schedule" in which:
         gen_schedule_and_sampler()
     if "rope" in which:
@@ -464,6 +528,8 @@ def main():
         gen_llm()
     if "titok" in which:
         gen_titok()
+    if "titok_enc" in which:
+        gen_titok_encoder()
     if "ups" in which:
         gen_upsampler()
     if "vae" in which:

@@ -178,6 +178,75 @@ def test_titok_decoder_fp32():
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=2e-5)
 
 
+def test_titok_encoder_fp32():
+    """TokenizerEncoderOracle.encode against TiTokEncoder.forward of the reference (tiny config, same seeded weights)."""
+    from landiff_amd.config import TokenizerConfig
+    from landiff_amd.weights import init_state, tokenizer_encoder_spec
+    from oracle.tokenizer import TokenizerEncoderOracle
+    g = load("titok_enc_fp32")
+    cfg = TokenizerConfig.tiny()
+    orc = TokenizerEncoderOracle(init_state(tokenizer_encoder_spec(cfg), int(g["seed"])), cfg, torch.float32)
+    out = orc.encode(T(g["x"]))                                        # [1, L, token_size]
+    ref = T(g["out"])[0, :, 0].t()                                     # reference returns [1, token_size, 1, L]
+    np.testing.assert_allclose(out[0].numpy(), ref.numpy(), rtol=0, atol=2e-5)
+
+
+def test_encoder_mask_closed_form_and_launch_labels():
+    """VideoEncoderMask: scalar and vectorised restatements equal the reference's mask (tiny dense; full size by sha256
+    and row counts), and the two-launch label scheme of the product (landiff_amd/tokenizer_encoder.py) reproduces it."""
+    from landiff_amd.config import TokenizerConfig
+    from landiff_amd.tokenizer_encoder import encoder_attention_labels
+    from oracle.tokenizer import encoder_mask_dense, encoder_mask_scalar
+    g = load("encoder_mask")
+
+    def from_labels(cfg, r0, r1):
+        qv, kv, ql, kl = encoder_attention_labels(cfg)
+        nv = cfg.n_visual
+        rows = np.arange(r0, min(r1, cfg.seq_len))
+        vis = kv[None, :].astype(np.int64) <= qv[rows][:, None]
+        lat = kl[None, :].astype(np.int64) <= ql[rows][:, None]
+        return np.where((rows < nv)[:, None], vis, lat)
+
+    Tn, tpf, nI, nP = g["tiny_cfg"].tolist()
+    cfg = TokenizerConfig(grid_h=1, grid_w=tpf, temporal=Tn, pframe_tokens=nP, num_latent_tokens=nI + (Tn - 1) * nP)
+    n = cfg.seq_len
+    scal = np.array([[encoder_mask_scalar(cfg, q, k) for k in range(n)] for q in range(n)])
+    assert np.array_equal(scal, g["tiny_dense"])
+    assert np.array_equal(encoder_mask_dense(cfg).numpy(), g["tiny_dense"])
+    assert np.array_equal(from_labels(cfg, 0, n), g["tiny_dense"])
+    Tn, tpf, nI, nP = g["full_cfg"].tolist()
+    cfg = TokenizerConfig()
+    assert (cfg.temporal, cfg.tokens_per_frame, cfg.iframe_tokens, cfg.pframe_tokens) == (Tn, tpf, nI, nP)
+    L = cfg.seq_len
+    h1, h2 = hashlib.sha256(), hashlib.sha256()
+    rows = np.zeros(L, np.int64)
+    for r0 in range(0, L, 128):
+        blk = encoder_mask_dense(cfg, r0, r0 + 128).numpy()
+        h1.update(np.packbits(blk.astype(np.uint8), axis=None).tobytes())
+        h2.update(np.packbits(from_labels(cfg, r0, r0 + 128).astype(np.uint8), axis=None).tobytes())
+        rows[r0:r0 + blk.shape[0]] = blk.sum(1)
+    assert np.array_equal(np.frombuffer(h1.digest(), dtype=np.uint8), g["full_sha256"])
+    assert np.array_equal(np.frombuffer(h2.digest(), dtype=np.uint8), g["full_sha256"])
+    assert np.array_equal(rows, g["full_row_counts"])
+
+
+def test_vq_nearest_code_round_trip():
+    """Nearest-code restatement (vector-quantize-pytorch, parity unpinned): the code vectors themselves map to their own
+    indices, and project_out(codebook[idx]) fed back through project_in's pseudo-inverse is not needed for that property."""
+    from landiff_amd.config import TokenizerConfig
+    from landiff_amd.weights import init_state, tokenizer_encoder_spec
+    from oracle.tokenizer import TokenizerEncoderOracle
+    cfg = TokenizerConfig.tiny()
+    sd = init_state(tokenizer_encoder_spec(cfg), 3)
+    # make project_in an exact left inverse on a 16-dim subspace: z = e @ pinv(W)^T  =>  W z + b = e when b = 0
+    W = sd["quantizer.project_in.weight"].double()
+    sd["quantizer.project_in.bias"].zero_()
+    e = sd["quantizer._codebook.embed"][0].double()
+    z = (e @ torch.linalg.pinv(W).t()).float()
+    orc = TokenizerEncoderOracle(sd, cfg, torch.float32)
+    assert torch.equal(orc.nearest_code(z), torch.arange(cfg.codebook_size))
+
+
 def test_upsampler_and_semantic_conv_fp32():
     from landiff_amd.config import TokenizerConfig, UpsamplerConfig
     from landiff_amd.weights import init_state, upsampler_spec
