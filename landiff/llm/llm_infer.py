@@ -38,6 +38,10 @@ class CodeTask:
     seed: int
     result: None | torch.Tensor = None
     sample_cfg: ARSampleCfg = field(default_factory=ARSampleCfg)
+    # use_gt_first_frame: semantic tokens of the conditioning video/first frame (LongTensor, at least the I frame), e.g. from
+    # landiff_amd.tokenizer_encoder.TokenizerEncoder.encode_to_index on its Theia feature maps.  (The reference reaches the
+    # same prefix through inputs["video"] of Semantic1DLM.tokenize, lm_model.py:315-352.)
+    first_frame_tokens: None | torch.Tensor = None
 
 
 class ArModelInferWrapper(torch.nn.Module):
@@ -54,14 +58,18 @@ class ArModelInferWrapper(torch.nn.Module):
     @torch.no_grad()
     def forward(self, code_task: CodeTask) -> CodeTask:
         sc = code_task.sample_cfg
-        if sc.teacher_forcing or sc.use_gt_first_frame:
-            # both need the tokenizer *encoder* half, which is outside the decode path
-            raise NotImplementedError("teacher_forcing/use_gt_first_frame need the tokenizer encoder (CLI defaults are off)")
+        if sc.teacher_forcing:
+            raise NotImplementedError("teacher_forcing replays a ground-truth token stream (training-time check); not on the inference path")
+        first = None
+        if sc.use_gt_first_frame:
+            if code_task.first_frame_tokens is None:
+                raise ValueError("use_gt_first_frame needs CodeTask.first_frame_tokens (TokenizerEncoder.encode_to_index output)")
+            first = code_task.first_frame_tokens.reshape(-1)[: self.config.iframe_len]
         text = encode_flan_t5([code_task.prompt], self.device_)[0]
         torch.manual_seed(code_task.seed)
         torch.cuda.manual_seed(code_task.seed)
         tokens = self.runner.sample(text, motion_score=sc.motion_score if sc.motion_score is not None else 0.0,
                                     num_frames=sc.num_frames, guidance_scale=sc.cfg, temperature=sc.temperature,
-                                    seed=code_task.seed, top_k=sc.top_k, top_p=sc.top_p)
+                                    seed=code_task.seed, top_k=sc.top_k, top_p=sc.top_p, first_frame_tokens=first)
         code_task.result = tokens.cpu().reshape(-1)
         return code_task

@@ -217,9 +217,13 @@ class LLMRunner:
     @torch.no_grad()
     def sample(self, text_emb: torch.Tensor, *, motion_score: float = 0.1, num_frames: int = 13, guidance_scale: float = 7.5,
                temperature: float = 1.0, seed: int | None = None, generator=None, use_graph: bool = False,
-               teacher_fed=None, logits_log=None, top_k: int | None = None, top_p: float | None = None) -> torch.Tensor:
+               teacher_fed=None, logits_log=None, top_k: int | None = None, top_p: float | None = None,
+               first_frame_tokens: torch.Tensor | None = None) -> torch.Tensor:
         """Returns the clamped visual token ids, int64 [n_visual] on the device (lm_model.py:509-516).
-        top_k / top_p filter the unrestricted positions inside the sampling kernel (lm_model.py:441-447)."""
+        top_k / top_p filter the unrestricted positions inside the sampling kernel (lm_model.py:441-447).
+        first_frame_tokens (int64 [iframe_len], e.g. from TokenizerEncoder.encode_to_index): use_gt_first_frame of the
+        reference (lm_model.py:332-352) -- the given I-frame tokens, END_OF_IFrame and the first START_OF_PFrame join the
+        prefilled prefix, sampling (and the RNG stream) starts at the first P token, the result begins with the given ids."""
         c, dev = self.cfg, self.dev
         self.top_k, self.top_p = top_k, top_p
         guided = guidance_scale > 0 and guidance_scale != 1
@@ -229,6 +233,15 @@ class LLMRunner:
         S = feats.shape[1] - 1
         full_len, forced, restricted, n_visual = forced_token_schedule(c, S, num_frames)
         assert full_len <= self.Lmax
+        S_last = S                                         # position of the last prefilled token
+        if first_frame_tokens is not None:
+            assert num_frames > 1 and first_frame_tokens.numel() == c.iframe_len, "first_frame_tokens: one I frame, more frames to sample"
+            ids = torch.cat([first_frame_tokens.reshape(-1).to(dev, torch.int64),
+                             torch.tensor([c.END_I, c.START_P], device=dev, dtype=torch.int64)])
+            assert forced[S + 1 + c.iframe_len] == c.END_I and forced[S + 2 + c.iframe_len] == c.START_P
+            feats = torch.cat([feats, self.emb[ids].to(BF)[None].expand(2, -1, -1)], 1)
+            S_last = S + c.iframe_len + 2
+            n_visual -= c.iframe_len
         ft = torch.full((self.Lmax + 2,), -1, dtype=torch.int32)
         al = torch.zeros(self.Lmax + 2, 4, dtype=torch.int32)
         for p, t in forced.items():
@@ -242,11 +255,11 @@ class LLMRunner:
             generator = torch.Generator(device=dev)
             generator.manual_seed(seed)                     # lm_model.py:398-402
         self._prefill(feats)
-        self.pos.fill_(S)
+        self.pos.fill_(S_last)
         self._sample_and_advance(guided, guidance_scale, temperature, generator)
         if logits_log is not None:
             logits_log.append(self.cfg_logits.clone())
-        steps = full_len - (S + 1) - 1
+        steps = full_len - (S_last + 1) - 1
         debug = teacher_fed is not None or logits_log is not None
         graph = None
         if use_graph and not debug and steps > 4:
@@ -264,7 +277,10 @@ class LLMRunner:
                 logits_log.append(self.cfg_logits.clone())
         self.host_enqueue_s = time.perf_counter() - t_enq      # host time to enqueue the loop (< wall time when the GPU is the bound)
         assert int(self.out_count.item()) == n_visual, (int(self.out_count.item()), n_visual)
-        return self.out_tokens[:n_visual].clamp(0, c.visual_vocab - 1)
+        out = self.out_tokens[:n_visual]
+        if first_frame_tokens is not None:
+            out = torch.cat([first_frame_tokens.reshape(-1).to(dev, torch.int64), out])
+        return out.clamp(0, c.visual_vocab - 1)
 
     def _capture(self, guided, scale, temperature, generator):
         """Capture one decode step (forward + sampling + advance) into a HIP graph."""

@@ -175,7 +175,7 @@ class LLMOracle:
     @torch.no_grad()
     def sample(self, text_emb, *, motion_score=0.1, num_frames=13, guidance_scale=7.5, temperature=1.0,
                top_k=None, top_p=None, multinomial_fn=None, generator=None, teacher_tokens=None,
-               return_logits=False):
+               return_logits=False, first_frame_tokens=None):
         """Semantic1DLM.sample (lm_model.py:293-516).  `multinomial_fn(probs[1,V]) -> LongTensor[1,1]`
         lets a test draw from the same RNG stream as the device under test; `teacher_tokens` (full
         token fed back after every loop iteration, forced positions included) overrides the fed-back
@@ -193,6 +193,14 @@ class LLMOracle:
         prefix_len = S + 1
         last = None
         sampled, all_logits = [], []
+        if first_frame_tokens is not None:
+            # use_gt_first_frame (lm_model.py:332-352): the prefix runs through [I tokens][END_OF_IFrame][START_OF_PFrame]
+            # (prefix_len = start_of_visual + 1) and the returned codes start with the given I tokens
+            ids = torch.cat([first_frame_tokens.reshape(-1).long(), torch.tensor([c.END_I, c.START_P])])
+            extra = emb[ids].to(feats.dtype)[None].expand(feats.shape[0], -1, -1)
+            feats = torch.cat([feats, extra], 1)
+            prefix_len = S + 1 + c.iframe_len + 2
+            sampled.append(first_frame_tokens.reshape(1, -1).long())
         for i in range(prefix_len, full_len):
             if last is not None:
                 f = emb[last].float()  # [1,1,hidden]

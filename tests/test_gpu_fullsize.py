@@ -149,3 +149,33 @@ def test_dit_layer_full_shape_vs_oracle(cuda):
     # bf16 activations through LN -> QKV -> attention -> gated residual -> MLP: a few bf16 ulps of the output range
     assert err.max().item() / scale < 3e-2, (err.max().item(), scale)
     assert err.mean().item() / ref.abs().mean().item() < 1e-2, (err.mean().item(), ref.abs().mean().item())
+
+
+def test_tokenizer_encoder_full_size_causality(cuda):
+    """Full-size encoder (13 x 30 x 45 visual + 1218 latent tokens, 12 layers): the mask's frame causality as a property.
+    Changing the features of frames >= f must leave the I tokens (f >= 1) and the P tokens of frames < f bit-identical --
+    every masked key contributes exactly zero and skipped tiles are skipped in both runs -- and must change the rest."""
+    import time
+    from landiff_amd.config import TokenizerConfig
+    from landiff_amd.tokenizer_encoder import TokenizerEncoder
+    from landiff_amd.weights import init_state, tokenizer_encoder_spec
+    cfg = TokenizerConfig()
+    enc = TokenizerEncoder(init_state(tokenizer_encoder_spec(cfg), 11, dtype=torch.bfloat16, device=cuda), cfg, cuda)
+    g = torch.Generator(device=cuda).manual_seed(3)
+    x = torch.randn(cfg.temporal, cfg.out_channels, cfg.grid_h, cfg.grid_w, device=cuda, generator=g)
+    base = enc.encode(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ids = enc.encode_to_index(x)
+    torch.cuda.synchronize()
+    print(f"full-size encode_to_index: {(time.perf_counter() - t0) * 1e3:.1f} ms")
+    assert ids.shape == (cfg.num_latent_tokens,) and int(ids.max()) < cfg.codebook_size
+    nI, nP = cfg.iframe_tokens, cfg.pframe_tokens
+    for f in (1, 7, 12):
+        y = x.clone()
+        y[f:] = torch.randn(cfg.temporal - f, cfg.out_channels, cfg.grid_h, cfg.grid_w, device=cuda, generator=g)
+        out = enc.encode(y)
+        keep = nI + (f - 1) * nP                    # I tokens + P tokens of frames 1..f-1
+        assert torch.equal(out[:keep], base[:keep]), f
+        assert not torch.equal(out[keep:keep + nP], base[keep:keep + nP]), f
+    assert torch.isfinite(base.float()).all()

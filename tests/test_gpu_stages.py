@@ -193,6 +193,40 @@ def test_llm_teacher_forced_logits_and_sampler(cuda, setup):
             assert tok in torch.topk(log3[step][0], 3).indices.cpu().tolist(), (i, tok)
 
 
+def test_llm_first_frame_conditioning(cuda, setup):
+    """use_gt_first_frame (lm_model.py:332-352): given I-frame tokens join the prefix; codes start with them, the P-frame
+    logits equal the oracle's (teacher-forced on the device's own history, same RNG stream for its draws)."""
+    from landiff_amd.llm import LLMRunner, forced_token_schedule
+    from oracle.llm import LLMOracle
+    cfg, st = setup
+    c = cfg.llm
+    g = torch.Generator().manual_seed(8)
+    text = torch.randn(6, c.text_dim, generator=g)
+    first = torch.randint(0, c.visual_vocab, (c.iframe_len,), generator=g)
+    run = LLMRunner(st["llm"], c, cuda, max_text=32, max_frames=c.segment_length)
+    gen = torch.Generator(device=cuda); gen.manual_seed(13)
+    log = []
+    codes = run.sample(text, num_frames=c.segment_length, guidance_scale=7.5, generator=gen, logits_log=log,
+                       first_frame_tokens=first.to(cuda))
+    S = text.shape[0] + 3
+    full_len, forced, _, n_vis = forced_token_schedule(c, S, c.segment_length)
+    assert codes.shape == (n_vis,) and torch.equal(codes[: c.iframe_len].cpu(), first)
+    dev_logits = torch.cat(log, 0).cpu()
+    raw = iter(run.out_tokens[: n_vis - c.iframe_len].cpu().tolist())
+    fed = [forced[i] if i in forced else next(raw) for i in range(S + 1 + c.iframe_len + 2, full_len)]
+    gen2 = torch.Generator(device=cuda); gen2.manual_seed(13)
+    orc = LLMOracle(st["llm"], c, torch.bfloat16)
+    ref_codes, ref_logits = orc.sample(text, num_frames=c.segment_length, guidance_scale=7.5, return_logits=True,
+                                       multinomial_fn=lambda p: torch.multinomial(p.to(cuda), 1, generator=gen2).cpu(),
+                                       teacher_tokens=torch.tensor(fed), first_frame_tokens=first)
+    assert dev_logits.shape == ref_logits.shape
+    err = (dev_logits - ref_logits).abs().max().item()
+    assert err < 0.35 * max(1.0, ref_logits.abs().max().item() / 10), err
+    assert torch.equal(ref_codes.reshape(-1)[: c.iframe_len], first)
+    agree = (ref_codes.reshape(-1) == codes.cpu()).float().mean().item()
+    assert agree >= 0.8, agree
+
+
 def test_llm_native_step_equals_per_op_step(cuda, setup):
     """ld_llm_decode_forward (the whole step queued by one native call) issues exactly the launches of the per-op path:
     same tokens from the same seed, eager and graph-replayed, and the same logits bit for bit on one step."""
