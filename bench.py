@@ -97,7 +97,10 @@ def main():
     import torch.distributed as dist
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    # LD_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1 takes the RCCL code path (init, barrier, all_gather,
+    # all_reduce) with a single rank: the only way to exercise it on a 1-GPU box (tests/test_gpu_variants.py)
+    use_dist = world > 1 or (os.environ.get("LD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
 
@@ -123,24 +126,24 @@ def main():
 
     def one_step():
         frames = pipe.generate_stream(inp, stream, prefix_frames=prefix) if stream else pipe(inp)
-        gathered = gather_frames(frames[None], world)
+        gathered = gather_frames(frames[None], world, force=use_dist)
         return gathered
 
     for _ in range(args.warmup):
         one_step()
     pipe.timings = {}
     pipe.dit.attn_events = []
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -177,7 +180,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(PipelineConfig.full())
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

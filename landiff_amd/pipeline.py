@@ -176,10 +176,11 @@ def shard_prompts(n_prompts: int, rank: int, world: int) -> list[int]:
     return list(range(rank, n_prompts, world))
 
 
-def gather_frames(frames: torch.Tensor, world: int):
-    """all_gather of uint8 frames [n_local, T, H, W, 3] over RCCL/xGMI (gloo on CPU in tests)."""
+def gather_frames(frames: torch.Tensor, world: int, force: bool = False):
+    """all_gather of uint8 frames [n_local, T, H, W, 3] over RCCL/xGMI (gloo on CPU in tests).
+    force: issue the collective even for a single rank (exercises the RCCL path on a 1-GPU box)."""
     import torch.distributed as dist
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized() or (world == 1 and not force):
         return [frames]
     out = [torch.empty_like(frames) for _ in range(world)]
     dist.all_gather(out, frames.contiguous())

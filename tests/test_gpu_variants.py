@@ -68,3 +68,26 @@ def test_gemm_main_loop_variants(cuda, env):
 @pytest.mark.parametrize("env", [{"LD_ATTN_SAFE": "1"}, {"LD_ATTN_NW": "8"}, {"LD_ATTN_NW": "8", "LD_ATTN_SAFE": "1"}, {"LD_ATTN_VARIANT": "9"}, {"LD_ATTN_VARIANT": "1"}, {"LD_ATTN_VARIANT": "4"}])
 def test_attention_variants(cuda, env):
     assert _run(ATTN_SNIPPET, env) < 2e-2
+
+
+def test_gemv_streaming_loop_variant(cuda):
+    """LD_GEMV_MODE=1 (the wave-per-row streaming kernel for every shape) against the same references as the default."""
+    e = dict(os.environ); e["LD_GEMV_MODE"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_gemv.py"), "-x", "-q", "-m", "gpu"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_rccl_path_single_rank(cuda):
+    """bench.py launched the way the driver launches the N-GPU runs (torch.distributed.run, one rank per GPU), with one
+    rank and LD_BENCH_FORCE_DIST=1: RCCL init, barrier, all_gather of the uint8 frames, all_reduce(MAX) of the time."""
+    import json
+    e = dict(os.environ); e["LD_BENCH_FORCE_DIST"] = "1"; e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--tiny",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["unit"] == "frames/s"
