@@ -193,6 +193,31 @@ def test_llm_teacher_forced_logits_and_sampler(cuda, setup):
             assert tok in torch.topk(log3[step][0], 3).indices.cpu().tolist(), (i, tok)
 
 
+def test_llm_token_ids_exact_for_a_confident_model(cuda, setup):
+    """Token-id parity where it is decidable: with a peaked next-token distribution (head weights x40, as in a trained
+    model) the device's ids equal the oracle's bit for bit under the same multinomial stream -- the flips of the flat
+    random model in the test above come from draws that land within bf16 logit noise of a CDF boundary."""
+    from landiff_amd.llm import LLMRunner, forced_token_schedule
+    from oracle.llm import LLMOracle
+    cfg, st = setup
+    c = cfg.llm
+    sd = dict(st["llm"])
+    sd["transformer.head.weight"] = sd["transformer.head.weight"] * 40.0
+    text = torch.randn(7, c.text_dim, generator=torch.Generator().manual_seed(4))
+    run = LLMRunner(sd, c, cuda, max_text=32, max_frames=c.segment_length)
+    gen = torch.Generator(device=cuda); gen.manual_seed(17)
+    codes = run.sample(text, num_frames=c.segment_length, guidance_scale=7.5, generator=gen)
+    S = text.shape[0] + 3
+    full_len, forced, _, n_vis = forced_token_schedule(c, S, c.segment_length)
+    raw = iter(run.out_tokens[:n_vis].cpu().tolist())
+    fed = [forced[i] if i in forced else next(raw) for i in range(S + 1, full_len)]
+    gen2 = torch.Generator(device=cuda); gen2.manual_seed(17)
+    ref = LLMOracle(sd, c, torch.bfloat16).sample(
+        text, num_frames=c.segment_length, guidance_scale=7.5, teacher_tokens=torch.tensor(fed),
+        multinomial_fn=lambda p: torch.multinomial(p.to(cuda), 1, generator=gen2).cpu())
+    assert torch.equal(ref.reshape(-1), codes.cpu()), (ref.reshape(-1) != codes.cpu()).sum().item()
+
+
 def test_llm_first_frame_conditioning(cuda, setup):
     """use_gt_first_frame (lm_model.py:332-352): given I-frame tokens join the prefix; codes start with them, the P-frame
     logits equal the oracle's (teacher-forced on the device's own history, same RNG stream for its draws)."""
