@@ -310,6 +310,20 @@ def load_llm_state(path: str) -> dict:
     return load_file(path)
 
 
+def load_tokenizer_encoder_state(path: str) -> dict:
+    """tokenizer/model.safetensors (VideoVQ state dict, tokenizer_cfg.py:104-118) -> the keys of tokenizer_encoder_spec:
+    encoder.*, quantizer.project_in.*, quantizer._codebook.embed and the feature mean/std buffers
+    (video_titok_vq.py:55-68; identity normalisation when the checkpoint carries no statistics)."""
+    from safetensors.torch import load_file
+    sd = load_file(path)
+    out = {k: v for k, v in sd.items()
+           if k.startswith("encoder.") or k.startswith("quantizer.project_in.") or k == "quantizer._codebook.embed"}
+    cin = out["encoder.patch_embed.weight"].shape[1]
+    out["mean"] = sd["mean"].reshape(-1).float() if "mean" in sd else torch.zeros(cin)
+    out["std"] = sd["std"].reshape(-1).float() if "std" in sd else torch.ones(cin)
+    return out
+
+
 def load_diffusion_states(diffusion_dir: str, root: str) -> dict:
     """Returns component state dicts from diffusion/<latest>/...pt plus the CogVideoX base DiT
     (keys 'model.diffusion_model.*', prefix 'model.' stripped as dit_video_concat.py:1176-1189 does;

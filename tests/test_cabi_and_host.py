@@ -129,3 +129,24 @@ def test_prompt_sharding():
     assert shard_prompts(8, 3, 8) == [3] and shard_prompts(10, 1, 4) == [1, 5, 9]
     allp = sorted(sum((shard_prompts(13, r, 4) for r in range(4)), []))
     assert allp == list(range(13))
+
+
+def test_tokenizer_encoder_checkpoint_loader(tmp_path):
+    """load_tokenizer_encoder_state picks exactly the encoder-half keys out of a VideoVQ safetensors file."""
+    import torch
+    from safetensors.torch import save_file
+    from landiff_amd.config import TokenizerConfig
+    from landiff_amd.weights import init_state, load_tokenizer_encoder_state, tokenizer_encoder_spec, tokenizer_spec
+    c = TokenizerConfig.tiny()
+    sd = init_state(tokenizer_encoder_spec(c), 1)
+    sd.update(init_state(tokenizer_spec(c), 2))                       # decoder half + project_out share the file
+    f = str(tmp_path / "model.safetensors")
+    save_file({k: v.contiguous() for k, v in sd.items()}, f)
+    out = load_tokenizer_encoder_state(f)
+    assert set(out) == {n for n, _, _ in tokenizer_encoder_spec(c)}
+    assert all(torch.equal(out[k].float(), sd[k].reshape(out[k].shape).float()) for k in out)
+    # no statistics in the file: identity normalisation
+    sd.pop("mean"); sd.pop("std")
+    save_file({k: v.contiguous() for k, v in sd.items()}, f)
+    out = load_tokenizer_encoder_state(f)
+    assert float(out["mean"].abs().max()) == 0.0 and float((out["std"] - 1).abs().max()) == 0.0
