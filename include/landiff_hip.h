@@ -73,6 +73,19 @@ int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int64_t ld
                     int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                     int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, void* stream);
 
+/* ---- optional fp8 (OCP e4m3) form of the DiT's large linear layers (BASELINE.json configs[4]; the headline metric and
+ * every parity claim of the bf16 path stay on ld_gemm_bf16) ---- */
+
+/* Row-wise dynamic quantisation of the activations in front of a Linear: x bf16 [rows][K] (row stride ldx) ->
+ * q e4m3 [rows][K] (row stride ldq bytes) and scale[r] = amax(row r) / 448 (1 for an all-zero row); q = rne(x / scale). */
+int ld_quantize_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t rows, int64_t K, void* stream);
+
+/* out[M][N] = epilogue(scale_a[m] * scale_w[n] * sum_k A8[m][k] * W8[n][k]): the same nn.Linear sites and the same
+ * epilogues as ld_gemm_bf16 (dit_video_concat.py:540-629), operands e4m3 (A8 row stride lda bytes, W8 [N][K] contiguous),
+ * fp32 accumulation on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales.  K % 128 == 0. */
+int ld_gemm_fp8(const void* A8, int64_t lda, const float* scale_a, const void* W8, const float* scale_w, void* out,
+                int64_t ldo, int64_t M, int64_t N, int64_t K, const ld_epilogue_t* epi, void* stream);
+
 /* Fused attention, head_dim 64: O = softmax(scale * Q K^T [+ frame mask]) V.
  * Q, K: bf16 [B*H][Npad][64]; Vt: bf16 [B*H][64][Npad] (V transposed, keys contiguous);
  * O: bf16, element (b, n, h*64 + d) at O + b*o_batch_stride + n*o_row_stride + h*64 + d.

@@ -52,6 +52,9 @@ struct GemmParams {
   int H, W_, Hp, Wp, Cin, kH, kW;   // output H,W; padded input Hp,Wp
   int group_m;                      // tile-raster group height (L2 locality)
   int m_begin;                      // first output row of this launch (rows stay absolute: M is the end row)
+  // fp8 (e4m3) operands: A and W are byte matrices (lda in bytes), dequantised by per-row / per-output-channel scales
+  const float* scale_a;             // [M]
+  const float* scale_w;             // [N]
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
@@ -456,6 +459,145 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   __syncthreads();
 
   gemm_epilogue<MI, NI, EPI>(p, acc, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) x fp8 -> fp32 GEMM for the DiT's four large linear layers (BASELINE config 5; never the headline
+// metric, which is bf16).  Same 256x256 tile / 8 waves (2 x 4, 128x64 per wave) / two-stage LDS-DMA structure as
+// ld_gemm_kernel: a K-tile is again 128 BYTES per row -- now 128 elements -- so the DMA pieces, the XOR swizzle and the
+// LDS footprint are unchanged while every tile carries twice the K.  v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales)
+// takes 32 bytes per lane per operand: row = lane % 32, k = 32 * (lane / 32) .. +32 within a 64-deep step (any K order
+// works as long as both operands use the same one; tools/probe/fp8_mfma_layout.hip), i.e. two adjacent 16-byte chunks.
+// The accumulator is dequantised in registers -- acc * scale_a[row] * scale_w[col] -- and then takes the ordinary
+// epilogues (bias / GELU / gated residual).
+// ------------------------------------------------------------------------------------------------
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void ld_gemm_f8_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, WN = 4, NW = 8, MI = 4, NI = 2;
+  constexpr int KB = 128;                                    // bytes (= elements) of K per tile
+  constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_LOADS = BM / 8 / NW, B_LOADS = BN / 8 / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, nbm * nbn);
+  const int gm_sz = p.group_m;
+  const int per_group = gm_sz * nbn;
+  const int group = bid / per_group, in_group = bid - group * per_group;
+  const int first_m = group * gm_sz;
+  const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+  const int m0 = (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
+  const char* A8 = (const char*)p.A;
+  const char* W8 = (const char*)p.W;
+
+  uint32_t offA[A_LOADS], offW[B_LOADS];                     // byte offsets (< 2^32: checked by the launcher)
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int r = (wave * A_LOADS + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+    offA[i] = (uint32_t)((long)gm * p.lda + chunk * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int r = (wave * B_LOADS + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+    offW[i] = (uint32_t)((long)gn * p.K + chunk * 16);
+  }
+  const int nk = p.K / KB;
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) glds16((const bf16_t*)(A8 + (offA[i] + (uint32_t)kt * KB)), base + (wave * A_LOADS + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) glds16((const bf16_t*)(W8 + (offW[i] + (uint32_t)kt * KB)), base + A_BYTES + (wave * B_LOADS + i) * 1024);
+  };
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int rdA[2][2], rdB[2][2];                                  // [64-deep step][16-byte half]
+  {
+    const int ra = wr * 128 + (lane & 31), rb = wc * 64 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = kk * 4 + (lane >> 5) * 2 + h;
+        rdA[kk][h] = ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4);
+        rdB[kk][h] = A_BYTES + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4);
+      }
+  }
+  auto frag = [&](int off) {
+    const u32x4_t lo = *(const u32x4_t*)(smem + off);
+    return lo;
+  };
+  auto compute = [&](auto bufc) {
+    constexpr int OFF = decltype(bufc)::value * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      i32x8_t a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const u32x4_t lo = frag(rdA[kk][0] + OFF + i * 4096), hi = frag(rdA[kk][1] + OFF + i * 4096);
+        a[i] = (i32x8_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const u32x4_t lo = frag(rdB[kk][0] + OFF + j * 4096), hi = frag(rdB[kk][1] + OFF + j * 4096);
+        b[j] = (i32x8_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 0, 0, 0, 127, 0, 127);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  stage(0, 0);
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    __syncthreads();
+    stage(1, kt + 1);
+    compute(std::integral_constant<int, 0>{});
+    __syncthreads();
+    if (kt + 2 < nk) stage(0, kt + 2);
+    compute(std::integral_constant<int, 1>{});
+  }
+  if (kt < nk) {
+    __syncthreads();
+    compute(std::integral_constant<int, 0>{});
+  }
+  __syncthreads();
+
+  // dequantise: acc[i][j][r] is C[row0 + 32 i + 8 (r / 4) + 4 (lane / 32) + r % 4][col0 + 32 j + lane % 32]
+  const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
+  float sw[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { const int gn = col0 + j * 32 + (lane & 31); sw[j] = p.scale_w[gn < p.N ? gn : p.N - 1]; }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gm = row0 + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+      const float sa = p.scale_a[gm < p.M ? gm : p.M - 1];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j][r] *= sa * sw[j];
+    }
+  gemm_epilogue<MI, NI, EPI>(p, acc, smem, wave, lane, row0, col0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1124,6 +1266,60 @@ int fill_epilogue(GemmParams& p, const ld_epilogue_t* e) {
   return LD_OK;
 }
 
+int launch_f8(const GemmParams& p, hipStream_t stream) {
+  constexpr int STAGE = (256 + 256) * 128;
+  constexpr int EPIB = 8 * 32 * CW_STRIDE * 4;
+  constexpr int SMEM = (2 * STAGE > EPIB) ? 2 * STAGE : EPIB;
+  const int nbm = (p.M + 255) / 256, nbn = (p.N + 255) / 256;
+  dim3 grid(nbm * nbn), block(512);
+  switch (pick_epilogue(p)) {
+    case EPI_BIAS: return launch_kernel<ld_gemm_f8_kernel<EPI_BIAS>>("ld_gemm_fp8", grid, block, SMEM, stream, p);
+    case EPI_GELU: return launch_kernel<ld_gemm_f8_kernel<EPI_GELU>>("ld_gemm_fp8", grid, block, SMEM, stream, p);
+    case EPI_GATE: return launch_kernel<ld_gemm_f8_kernel<EPI_GATE>>("ld_gemm_fp8", grid, block, SMEM, stream, p);
+    default: return launch_kernel<ld_gemm_f8_kernel<EPI_GENERIC>>("ld_gemm_fp8", grid, block, SMEM, stream, p);
+  }
+}
+
+// Row-wise dynamic quantisation to OCP e4m3: scale[r] = amax(row) / 448 (1 for an all-zero row), q = cvt(x / scale).
+// One wave per row, the row stays in registers between the two passes (K <= 8192: 16 chunks of 8 per lane).
+__global__ __launch_bounds__(256) void ld_quant_fp8_kernel(const bf16_t* x, long ldx, unsigned char* q, long ldq, float* scale,
+                                                           int rows, int K) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int nchunk = K >> 3;
+  u32x4_t v[16];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = (u32x4_t){0u, 0u, 0u, 0u};
+    if (c < nchunk) v[i] = *(const u32x4_t*)(x + (long)r * ldx + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bf_lo(v[i][e])), fabsf(bf_hi(v[i][e]))));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[r] = sc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i;
+    if (c >= nchunk) continue;
+    u32x2_t o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float f0 = fminf(fmaxf(bf_lo(v[i][2 * h]) * inv, -448.f), 448.f), f1 = fminf(fmaxf(bf_hi(v[i][2 * h]) * inv, -448.f), 448.f);
+      const float f2 = fminf(fmaxf(bf_lo(v[i][2 * h + 1]) * inv, -448.f), 448.f), f3 = fminf(fmaxf(bf_hi(v[i][2 * h + 1]) * inv, -448.f), 448.f);
+      unsigned w = 0;
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(f2, f3, w, true);
+      o[h] = w;
+    }
+    *(u32x2_t*)(q + (long)r * ldq + c * 8) = o;
+  }
+}
+
 }  // namespace
 
 LD_API int ld_gemm_bf16(const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
@@ -1159,4 +1355,30 @@ LD_API int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int
   int rc = fill_epilogue(p, epi);
   if (rc) return rc;
   return launch(p, true, (hipStream_t)stream);
+}
+
+LD_API int ld_quantize_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t rows, int64_t K,
+                           void* stream) {
+  LD_REQUIRE(x && q && scale && rows > 0, "ld_quantize_fp8: bad args");
+  LD_REQUIRE(K % 8 == 0 && K <= 8192 && ldx % 8 == 0 && ldq % 8 == 0, "ld_quantize_fp8: K=%ld must be a multiple of 8 and <= 8192", (long)K);
+  hipLaunchKernelGGL(ld_quant_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (long)ldx, (unsigned char*)q, (long)ldq, scale, (int)rows, (int)K);
+  return ld_check_launch("ld_quantize_fp8");
+}
+
+LD_API int ld_gemm_fp8(const void* A8, int64_t lda, const float* scale_a, const void* W8, const float* scale_w, void* out,
+                       int64_t ldo, int64_t M, int64_t N, int64_t K, const ld_epilogue_t* epi, void* stream) {
+  LD_REQUIRE(A8 && W8 && out && scale_a && scale_w, "ld_gemm_fp8: null pointer");
+  LD_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0, "ld_gemm_fp8: K=%ld must be a positive multiple of 128", (long)K);
+  LD_REQUIRE(lda % 16 == 0 && ((uintptr_t)A8 & 15) == 0 && ((uintptr_t)W8 & 15) == 0 && ((uintptr_t)out & 15) == 0,
+             "ld_gemm_fp8: lda and pointers must be 16-byte aligned");
+  LD_REQUIRE(M * lda < (1LL << 32) && N * K < (1LL << 32), "ld_gemm_fp8: operand larger than 4 GiB");
+  GemmParams p{};
+  p.A = (const bf16_t*)A8; p.W = (const bf16_t*)W8; p.out = out;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = lda; p.ldo = ldo;
+  p.scale_a = scale_a; p.scale_w = scale_w;
+  p.group_m = 8;
+  int rc = fill_epilogue(p, epi);
+  if (rc) return rc;
+  return launch_f8(p, (hipStream_t)stream);
 }

@@ -86,6 +86,38 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, **ep
     return out
 
 
+def quantize_fp8(x: torch.Tensor, q: torch.Tensor | None = None, scale: torch.Tensor | None = None):
+    """Row-wise dynamic e4m3 quantisation: x bf16 [M,K] -> (q uint8 [M,K], scale fp32 [M]); x ~= q * scale[:, None]."""
+    _bf16(x, "x")
+    M, K = x.shape
+    assert x.stride(1) == 1
+    if q is None:
+        q = torch.empty(M, K, device=x.device, dtype=torch.uint8)
+    if scale is None:
+        scale = torch.empty(M, device=x.device, dtype=torch.float32)
+    assert q.dtype == torch.uint8 and q.shape == (M, K) and q.stride(1) == 1 and scale.dtype == torch.float32 and scale.is_contiguous()
+    check(_lib.load().ld_quantize_fp8(_ptr(x), x.stride(0), _ptr(q), q.stride(0), _ptr(scale), M, K, _stream()), "ld_quantize_fp8")
+    return q, scale
+
+
+def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, w8: torch.Tensor, scale_w: torch.Tensor,
+             out: torch.Tensor | None = None, **epi) -> torch.Tensor:
+    """out[M,N] = epilogue((a8 * scale_a[:,None]) @ (w8 * scale_w[:,None])^T), e4m3 operands as uint8 tensors."""
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(1) == 1 and w8.is_contiguous()
+    M, K = a8.shape
+    N = w8.shape[0]
+    assert w8.shape[1] == K and scale_a.shape == (M,) and scale_w.shape == (N,)
+    assert scale_a.dtype == torch.float32 and scale_w.dtype == torch.float32 and scale_a.is_contiguous() and scale_w.is_contiguous()
+    out_f32 = bool(epi.get("out_f32", False))
+    if out is None:
+        out = torch.empty((M, N), device=a8.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    assert out.stride(1) == 1 and out.shape == (M, N) and (out.dtype == torch.float32) == out_f32
+    e = make_epilogue(**epi)
+    check(_lib.load().ld_gemm_fp8(_ptr(a8), a8.stride(0), _ptr(scale_a), _ptr(w8), _ptr(scale_w), _ptr(out), out.stride(0),
+                                  M, N, K, ctypes.byref(e), _stream()), "ld_gemm_fp8")
+    return out
+
+
 def conv_cl(x_padded: torch.Tensor, w: torch.Tensor, T: int, H: int, W: int,
             out: torch.Tensor | None = None, **epi) -> torch.Tensor:
     """Channels-last conv.  x_padded [T+kT-1, H+kH-1, W+kW-1, Cin]; w [Cout, kT, kH, kW, Cin]."""
