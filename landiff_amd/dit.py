@@ -25,7 +25,7 @@ def _dev(t, device, dtype=BF):
 class _Branch:
     """Packed weights of one DiffusionTransformer (control or main)."""
 
-    def __init__(self, sd: dict, cfg: DiTConfig, control: bool, device):
+    def __init__(self, sd: dict, cfg: DiTConfig, control: bool, device, fp8_gemm: bool = False):
         d = cfg.hidden
         self.control = control
         self.L = cfg.layers_control if control else cfg.layers_main
@@ -53,6 +53,9 @@ class _Branch:
             )
             if control:
                 lw["zero_w"] = g(a + f"zero_linears.{i}.weight")
+            if fp8_gemm:      # e4m3 weights, one scale per output channel; the bf16 copies of the four big matrices go
+                for name in ("qkv", "dense", "h4", "h1"):
+                    lw[name + "_w8"], lw[name + "_s"] = ops.quantize_fp8(lw.pop(name + "_w"))
             self.layers.append(lw)
         if not control:
             f = "mixins.final_layer."
@@ -67,10 +70,13 @@ class ControlDiTRunner:
 
     B = 2
 
-    def __init__(self, main_sd: dict, control_sd: dict, cfg: DiTConfig, device):
-        self.cfg, self.dev = cfg, device
-        self.main = _Branch(main_sd, cfg, False, device)
-        self.ctrl = _Branch(control_sd, cfg, True, device)
+    def __init__(self, main_sd: dict, control_sd: dict, cfg: DiTConfig, device, fp8_gemm: bool = False):
+        """fp8_gemm: BASELINE configs[4] -- the qkv / dense / 4h / 4h->h linears run on e4m3 operands (weights quantised
+        once per output channel, activations per row in front of each GEMM); attention, norms, residual stream and every
+        other layer stay bf16.  Off for the headline metric and for every parity claim of the bf16 path."""
+        self.cfg, self.dev, self.fp8 = cfg, device, fp8_gemm
+        self.main = _Branch(main_sd, cfg, False, device, fp8_gemm)
+        self.ctrl = _Branch(control_sd, cfg, True, device, fp8_gemm)
         c, B = cfg, self.B
         d, N = c.hidden, c.seq_len
         M = B * N
@@ -97,6 +103,9 @@ class ControlDiTRunner:
         self.tvec = e(B, dt=torch.float32)
         self.txt_main = e(B, c.text_len, d)
         self.txt_ctrl = e(B, c.text_len, d)
+        if fp8_gemm:
+            self.a8 = torch.empty(M, 4 * d, device=device, dtype=torch.uint8)    # quantised GEMM input (largest K)
+            self.sa = e(M, dt=torch.float32)
         self.sem = None                         # [T, C, H, W] bf16, set per video
         self.attn_events = None                 # bench.py: list of (start, end) HIP events around every attention launch
 
@@ -127,6 +136,15 @@ class ControlDiTRunner:
             ops.gemm(self.patches, br.patch_w, out=hv[b, c.text_len:], bias=br.patch_b, add2=br.pos[c.text_len:])
             hv[b, :c.text_len].copy_(txt[b])
 
+    def _linear(self, x: torch.Tensor, lw: dict, name: str, out: torch.Tensor, **epi):
+        """One of the four large nn.Linear sites of a block: bf16 MFMA GEMM, or (fp8_gemm) quantise + e4m3 GEMM."""
+        if not self.fp8:
+            return ops.gemm(x, lw[name + "_w"], out=out, bias=lw[name + "_b"], **epi)
+        K = x.shape[1]
+        a8 = self.a8.view(-1)[: x.shape[0] * K].view(x.shape[0], K)
+        ops.quantize_fp8(x, a8, self.sa)
+        return ops.gemm_fp8(a8, self.sa, lw[name + "_w8"], lw[name + "_s"], out=out, bias=lw[name + "_b"], **epi)
+
     def _layer(self, br: _Branch, i: int, h_in: torch.Tensor, h_out: torch.Tensor, control_add=None):
         c, lw = self.cfg, br.layers[i]
         d, N = c.hidden, self.N
@@ -134,7 +152,7 @@ class ControlDiTRunner:
         ops.gemv(self.emb, lw["ada_w"], self.ada, bias=lw["ada_b"], in_act="silu")
         ops.layernorm(h_in, lw["ln1_w"], lw["ln1_b"], self.ln, c.block_ln_eps, shift_img=0, scale_img=d,
                       shift_txt=6 * d, scale_txt=7 * d, **mod)
-        ops.gemm(self.ln, lw["qkv_w"], out=self.qkv, bias=lw["qkv_b"])
+        self._linear(self.ln, lw, "qkv", self.qkv)
         ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
         if self.attn_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -145,13 +163,11 @@ class ControlDiTRunner:
         else:
             ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5)
         gate = dict(gate=self.ada, gate_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
-        ops.gemm(self.attn.view(-1, d), lw["dense_w"], out=h_out, bias=lw["dense_b"], resid=h_in,
-                 gate_off_img=2 * d, gate_off_txt=8 * d, **gate)
+        self._linear(self.attn.view(-1, d), lw, "dense", h_out, resid=h_in, gate_off_img=2 * d, gate_off_txt=8 * d, **gate)
         ops.layernorm(h_out, lw["ln2_w"], lw["ln2_b"], self.ln, c.block_ln_eps, shift_img=3 * d, scale_img=4 * d,
                       shift_txt=9 * d, scale_txt=10 * d, **mod)
-        ops.gemm(self.ln, lw["h4_w"], out=self.mlp, bias=lw["h4_b"], act="gelu_tanh")
-        ops.gemm(self.mlp, lw["h1_w"], out=h_out, bias=lw["h1_b"], resid=h_out, gate_off_img=5 * d,
-                 gate_off_txt=11 * d, add2=control_add, **gate)
+        self._linear(self.ln, lw, "h4", self.mlp, act="gelu_tanh")
+        self._linear(self.mlp, lw, "h1", h_out, resid=h_out, gate_off_img=5 * d, gate_off_txt=11 * d, add2=control_add, **gate)
 
     # ---- one denoiser evaluation -----------------------------------------------------------
     def step(self, x: torch.Tensor, timestep: int, c_out: float, c_skip: float, cfg_scale: float, out: torch.Tensor):

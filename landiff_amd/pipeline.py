@@ -33,7 +33,8 @@ class PromptInputs:
 
 
 class LanDiffPipeline:
-    def __init__(self, cfg: PipelineConfig, states: dict, device="cuda:0", max_llm_frames: int | None = None):
+    def __init__(self, cfg: PipelineConfig, states: dict, device="cuda:0", max_llm_frames: int | None = None,
+                 fp8_gemm: bool = False):
         if not torch.cuda.is_available():
             raise _lib.LandiffHipError("LanDiffPipeline needs an MI355X GPU: there is no CPU fallback")
         _lib.load()
@@ -44,7 +45,8 @@ class LanDiffPipeline:
         self.llm = LLMRunner(states["llm"], cfg.llm, self.dev,
                              max_frames=max_llm_frames or cfg.llm.segment_length) if "llm" in states else None
         self.detok = Detokenizer(states["tok"], states["ups"], cfg.tok, cfg.ups, self.dev)
-        self.dit = ControlDiTRunner(states["dit_main"], states["dit_control"], cfg.dit, self.dev)
+        # fp8_gemm: BASELINE configs[4] (e4m3 operands for the DiT's four large linears); never the headline configuration
+        self.dit = ControlDiTRunner(states["dit_main"], states["dit_control"], cfg.dit, self.dev, fp8_gemm=fp8_gemm)
         self.sampler = DiffusionSampler(cfg.sampler)
         self.vae = VAEDecoder(states["vae"], cfg.vae, self.dev)
         self.timings = {}

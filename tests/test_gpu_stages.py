@@ -59,6 +59,27 @@ def test_dit_denoise_step(cuda, setup):
     assert rel(out, den_c) < 2e-2, rel(out, den_c)
 
 
+def test_dit_fp8_linears_close_to_bf16(cuda, setup):
+    """configs[4]: the same denoiser step with e4m3 operands on the four large linears stays within the format's noise of
+    the bf16 step (and is not the bf16 step)."""
+    from landiff_amd.dit import ControlDiTRunner
+    cfg, st = setup
+    d = cfg.dit
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, d.latent_frames, d.in_channels, d.latent_h, d.latent_w, generator=g).to(cuda)
+    ctx = torch.randn(1, d.text_len, d.text_dim, generator=g)
+    sem = torch.randn(d.latent_frames, d.in_channels, d.latent_h, d.latent_w, generator=g).to(torch.bfloat16)
+    outs = []
+    for fp8 in (False, True):
+        run = ControlDiTRunner(st["dit_main"], st["dit_control"], d, cuda, fp8_gemm=fp8)
+        run.set_condition(ctx, sem)
+        out = torch.empty_like(x)
+        run.step(x, 500, -0.7, 0.7, 1.0, out)           # scale 1: the cond branch alone (CFG would amplify the noise)
+        outs.append(out.float().cpu())
+    rel = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()
+    assert 1e-5 < rel < 0.1, rel
+
+
 def test_sampler_loop_matches_oracle(cuda, setup):
     """Same analytic denoiser on both sides, same injected noise: the device loop must reproduce the oracle's
     trajectory to fp32 rounding (pins multipliers, RNG call order and the elementwise kernels)."""
