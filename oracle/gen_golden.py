@@ -209,6 +209,8 @@ def gen_llm():
     class FakeTok(nn.Module):
         segment_length, segment_stride = cfg.segment_length, cfg.segment_stride
         def vocab_size(self): return cfg.visual_vocab
+        def encode_codes(self, visual):           # use_gt_first_frame run: inputs["video"] carries the token ids themselves
+            return [visual.long()]
 
     class FakeT5(nn.Module):
         dimension, max_length = cfg.text_dim, 512
@@ -270,6 +272,16 @@ def gen_llm():
             extra["codes_2seg"] = model.sample(inputs, guidance_scale=7.5, temperature=1.0, seed=None,
                                                num_frames=2 * cfg.segment_length)
         save(f"llm_{tag}", text=text, codes=codes, logits=logits, fed_tokens=fed_tokens, seed=np.array(5), **extra)
+        if tag == "fp32":   # use_gt_first_frame (lm_model.py:332-352): the I frame of a given token stream joins the prefix
+            logits_log.clear()
+            n_codes = cfg.iframe_len + (cfg.segment_length - 1) * cfg.pframe_len
+            gt = torch.randint(0, cfg.visual_vocab, (n_codes,), generator=g)
+            inputs["frames"] = torch.tensor([float(cfg.segment_length)])
+            inputs["video"] = [gt.float()]
+            torch.manual_seed(44)
+            codes_gt = model.sample(inputs, guidance_scale=7.5, temperature=1.0, seed=None, num_frames=cfg.segment_length,
+                                    use_gt_first_frame=True)
+            save("llm_fp32_gt_first_frame", text=text, gt=gt, codes=codes_gt, logits=torch.cat(logits_log, 0).clone(), seed=np.array(5))
 
 
 # ------------------------------------------------------------------------------------------

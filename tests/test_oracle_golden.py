@@ -138,6 +138,22 @@ def test_llm_fp32_logits_and_tokens():
     assert np.array_equal(codes2.numpy(), g["codes_2seg"])
 
 
+def test_llm_gt_first_frame_fp32():
+    """use_gt_first_frame (lm_model.py:332-352) of the reference's Semantic1DLM.sample: the I frame of a given token stream
+    is prefilled, sampling starts at the first P token; ids bit-exact (same CPU RNG stream), CFG logits of every step."""
+    g, cfg, orc = _llm("fp32", torch.float32)
+    gt = load("llm_fp32_gt_first_frame")
+    first = T(gt["gt"])[: cfg.iframe_len]
+    torch.manual_seed(44)
+    codes, logits = orc.sample(T(gt["text"]), motion_score=0.1, num_frames=cfg.segment_length, guidance_scale=7.5,
+                               return_logits=True, first_frame_tokens=first)
+    assert np.array_equal(codes.numpy(), gt["codes"])
+    assert np.array_equal(codes.numpy()[0, : cfg.iframe_len], gt["gt"][: cfg.iframe_len])
+    ref = T(gt["logits"]).view(-1, 2, cfg.vocab)
+    ref_cfg = ref[:, 1] + 7.5 * (ref[:, 0] - ref[:, 1])
+    np.testing.assert_allclose(logits.numpy(), ref_cfg.numpy(), rtol=0, atol=2e-4)
+
+
 def test_llm_bf16_dtype_flow():
     """bf16 mode follows the reference's autocast flow (reference run under CPU autocast)."""
     g, cfg, orc = _llm("bf16", torch.bfloat16)
