@@ -282,6 +282,13 @@ def gen_llm():
             codes_gt = model.sample(inputs, guidance_scale=7.5, temperature=1.0, seed=None, num_frames=cfg.segment_length,
                                     use_gt_first_frame=True)
             save("llm_fp32_gt_first_frame", text=text, gt=gt, codes=codes_gt, logits=torch.cat(logits_log, 0).clone(), seed=np.array(5))
+            # top-k / top-p filtering of the unrestricted positions (lm_model.py:441-447, top_p_probability)
+            del inputs["video"]
+            torch.manual_seed(45)
+            codes_k = model.sample(inputs, guidance_scale=7.5, temperature=1.0, seed=None, num_frames=cfg.segment_length, top_k=5)
+            torch.manual_seed(46)
+            codes_p = model.sample(inputs, guidance_scale=7.5, temperature=0.7, seed=None, num_frames=cfg.segment_length, top_p=0.8)
+            save("llm_fp32_topk_topp", text=text, codes_top_k5=codes_k, codes_top_p08_t07=codes_p, seed=np.array(5))
 
 
 # ------------------------------------------------------------------------------------------

@@ -154,6 +154,18 @@ def test_llm_gt_first_frame_fp32():
     np.testing.assert_allclose(logits.numpy(), ref_cfg.numpy(), rtol=0, atol=2e-4)
 
 
+def test_llm_top_k_top_p_fp32():
+    """top-k and top-p sampling (lm_model.py:441-447) against the reference's own runs: ids bit-exact on the CPU RNG stream."""
+    g, cfg, orc = _llm("fp32", torch.float32)
+    gk = load("llm_fp32_topk_topp")
+    torch.manual_seed(45)
+    ck = orc.sample(T(gk["text"]), motion_score=0.1, num_frames=cfg.segment_length, guidance_scale=7.5, top_k=5)
+    assert np.array_equal(ck.numpy(), gk["codes_top_k5"])
+    torch.manual_seed(46)
+    cp = orc.sample(T(gk["text"]), motion_score=0.1, num_frames=cfg.segment_length, guidance_scale=7.5, temperature=0.7, top_p=0.8)
+    assert np.array_equal(cp.numpy(), gk["codes_top_p08_t07"])
+
+
 def test_llm_bf16_dtype_flow():
     """bf16 mode follows the reference's autocast flow (reference run under CPU autocast)."""
     g, cfg, orc = _llm("bf16", torch.bfloat16)
