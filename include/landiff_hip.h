@@ -86,6 +86,17 @@ int ld_quantize_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* sca
 int ld_gemm_fp8(const void* A8, int64_t lda, const float* scale_a, const void* W8, const float* scale_w, void* out,
                 int64_t ldo, int64_t M, int64_t N, int64_t K, const ld_epilogue_t* epi, void* stream);
 
+/* MXFP8 form of the same (OCP Microscaling v1.0 container: blocks of 32 consecutive K elements share one E8M0 scale;
+ * here the smallest power of two >= amax / 448, so nothing saturates; elements are e4m3 casts of x / scale).
+ * scales: uint8 [rows][lds >= K/32] (byte = exponent + 127; 0 for an all-zero block). */
+int ld_quantize_mxfp8(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds, int64_t rows,
+                      int64_t K, void* stream);
+
+/* out = epilogue(sum over blocks of 2^(sa-127) 2^(sw-127) sum_{k in block} A8[m][k] W8[n][k]): the block scales are
+ * applied by v_mfma_scale_f32_32x32x64_f8f6f4 itself.  scales_a [M][K/32], scales_w [N][K/32] contiguous. K % 128 == 0. */
+int ld_gemm_mxfp8(const void* A8, int64_t lda, const void* scales_a, const void* W8, const void* scales_w, void* out,
+                  int64_t ldo, int64_t M, int64_t N, int64_t K, const ld_epilogue_t* epi, void* stream);
+
 /* Fused attention, head_dim 64: O = softmax(scale * Q K^T [+ frame mask]) V.
  * Q, K: bf16 [B*H][Npad][64]; Vt: bf16 [B*H][64][Npad] (V transposed, keys contiguous);
  * O: bf16, element (b, n, h*64 + d) at O + b*o_batch_stride + n*o_row_stride + h*64 + d.

@@ -118,6 +118,40 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, w8: torch.Tensor, scale_w:
     return out
 
 
+def quantize_mxfp8(x: torch.Tensor, q: torch.Tensor | None = None, scales: torch.Tensor | None = None):
+    """MXFP8 quantisation: x bf16 [M,K] -> (q uint8 [M,K] e4m3 codes, scales uint8 [M,K/32] E8M0 bytes)."""
+    _bf16(x, "x")
+    M, K = x.shape
+    assert x.stride(1) == 1 and K % 32 == 0
+    if q is None:
+        q = torch.empty(M, K, device=x.device, dtype=torch.uint8)
+    if scales is None:
+        scales = torch.empty(M, K // 32, device=x.device, dtype=torch.uint8)
+    assert q.dtype == torch.uint8 and q.shape == (M, K) and q.stride(1) == 1
+    assert scales.dtype == torch.uint8 and scales.shape == (M, K // 32) and scales.stride(1) == 1
+    check(_lib.load().ld_quantize_mxfp8(_ptr(x), x.stride(0), _ptr(q), q.stride(0), _ptr(scales), scales.stride(0), M, K,
+                                        _stream()), "ld_quantize_mxfp8")
+    return q, scales
+
+
+def gemm_mxfp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, out: torch.Tensor | None = None,
+               **epi) -> torch.Tensor:
+    """out[M,N] = epilogue(dequant(a8, sa) @ dequant(w8, sw)^T) with the MX block scales applied inside the MFMA."""
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(1) == 1 and w8.is_contiguous()
+    M, K = a8.shape
+    N = w8.shape[0]
+    assert w8.shape[1] == K and tuple(sa.shape) == (M, K // 32) and tuple(sw.shape) == (N, K // 32)
+    assert sa.dtype == torch.uint8 and sw.dtype == torch.uint8 and sa.is_contiguous() and sw.is_contiguous()
+    out_f32 = bool(epi.get("out_f32", False))
+    if out is None:
+        out = torch.empty((M, N), device=a8.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    assert out.stride(1) == 1 and out.shape == (M, N) and (out.dtype == torch.float32) == out_f32
+    e = make_epilogue(**epi)
+    check(_lib.load().ld_gemm_mxfp8(_ptr(a8), a8.stride(0), _ptr(sa), _ptr(w8), _ptr(sw), _ptr(out), out.stride(0),
+                                    M, N, K, ctypes.byref(e), _stream()), "ld_gemm_mxfp8")
+    return out
+
+
 def conv_cl(x_padded: torch.Tensor, w: torch.Tensor, T: int, H: int, W: int,
             out: torch.Tensor | None = None, **epi) -> torch.Tensor:
     """Channels-last conv.  x_padded [T+kT-1, H+kH-1, W+kW-1, Cin]; w [Cout, kT, kH, kW, Cin]."""

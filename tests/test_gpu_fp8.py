@@ -77,3 +77,80 @@ def test_fp8_chain_vs_bf16_gemm(cuda):
     rel = ((out8 - out16).norm() / out16.norm()).item()
     assert rel < 0.05, rel                                           # e4m3: 3 mantissa bits on both operands
     assert rel > 1e-4                                                # ... and it really is the fp8 path
+
+
+# ---------------------------------------------------------------------------------------------- MXFP8
+def _mx_quant_ref(x):
+    """MX container reference: per 32 elements one E8M0 scale = the smallest power of two >= amax / 448 (fp32 arithmetic as
+    in the kernel), elements = e4m3 cast of x / scale."""
+    M, K = x.shape
+    xb = x.float().view(M, K // 32, 32)
+    amax = xb.abs().amax(-1)
+    tb = (amax * torch.tensor(1.0 / 448.0, dtype=torch.float32)).view(torch.int32)
+    sb = ((tb >> 23) & 0xff) + ((tb & 0x7fffff) != 0).to(torch.int32)
+    sb = torch.where(amax > 0, sb.clamp(1, 254), torch.zeros_like(sb))
+    inv = torch.pow(2.0, (127 - sb).float())
+    q = (xb * inv[..., None]).clamp(-448, 448).to(F8).view(torch.uint8).view(M, K)
+    return q, sb.to(torch.uint8)
+
+
+def _mx_deq(q, sb):
+    M, K = q.shape
+    return (q.view(F8).float().view(M, K // 32, 32) * torch.pow(2.0, sb.float() - 127)[..., None]).view(M, K)
+
+
+@pytest.mark.parametrize("M,K", [(7, 128), (300, 1920), (129, 7680)])
+def test_quantize_mxfp8(cuda, M, K):
+    from landiff_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(-4, 3, K)[None, :]).to(BF)      # wildly different block magnitudes
+    x[M // 2, 32:96] = 0
+    q, sb = ops.quantize_mxfp8(x.to(cuda))
+    wq, ws = _mx_quant_ref(x)
+    assert torch.equal(sb.cpu(), ws)
+    assert torch.equal(q.cpu(), wq)
+    rel = ((_mx_deq(q.cpu(), sb.cpu()) - x.float()).norm() / x.float().norm()).item()
+    assert rel < 0.05, rel
+
+
+@pytest.mark.parametrize("M,N,K,form", [(256, 256, 128, "plain"), (300, 200, 256, "bias"), (1000, 1920, 1920, "gelu"), (777, 1920, 7680, "resid")])
+def test_gemm_mxfp8_exact_operands(cuda, M, N, K, form):
+    from landiff_amd import ops
+    g = torch.Generator().manual_seed(M * 5 + N)
+    a = (torch.randn(M, K, generator=g) * torch.logspace(-2, 1, K // 32).repeat_interleave(32)[None, :]).to(BF)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    a8, sa = _mx_quant_ref(a)
+    w8, sw = _mx_quant_ref(w)
+    ref = _mx_deq(a8, sa).double() @ _mx_deq(w8, sw).double().t()
+    kw, post = {}, (lambda r: r)
+    if form in ("bias", "gelu", "resid"):
+        bias = torch.randn(N, generator=g).to(BF)
+        kw["bias"] = bias.to(cuda)
+        ref = ref + bias.double()
+    if form == "gelu":
+        kw["act"] = "gelu_tanh"
+        post = lambda r: torch.nn.functional.gelu(r.float().to(BF).float(), approximate="tanh")
+    if form == "resid":
+        res = torch.randn(M, N, generator=g).to(BF)
+        kw["resid"] = res.to(cuda)
+        post = lambda r: res.float() + r.float().to(BF).float()
+    out = ops.gemm_mxfp8(a8.to(cuda), sa.to(cuda), w8.to(cuda), sw.to(cuda), **kw)
+    want = post(ref.float())
+    err = (out.float().cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-6)
+    assert err < 1e-2, err
+
+
+def test_mxfp8_chain_vs_bf16_gemm(cuda):
+    from landiff_amd import ops
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 4096, 1920, 1920
+    a = torch.randn(M, K, generator=g).to(cuda, BF)
+    a[:, ::97] *= 30.0                                               # outlier columns: the case block scaling is for
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda, BF)
+    out16 = ops.gemm(a, w).float()
+    a8, sa = ops.quantize_mxfp8(a); w8, sw = ops.quantize_mxfp8(w)
+    rel_mx = ((ops.gemm_mxfp8(a8, sa, w8, sw).float() - out16).norm() / out16.norm()).item()
+    q8, s8 = ops.quantize_fp8(a); v8, t8 = ops.quantize_fp8(w)
+    rel_row = ((ops.gemm_fp8(q8, s8, v8, t8).float() - out16).norm() / out16.norm()).item()
+    assert rel_mx < 0.05, rel_mx
+    assert rel_mx < 1.25 * rel_row, (rel_mx, rel_row)                # e4m3 is floating point: both sit at its ~2^-4 relative step
