@@ -64,7 +64,8 @@ SIGNATURES: dict[str, list] = {
     "ld_quantize_fp8": [P, I64, P, I64, P, I64, I64, P],
     "ld_gemm_fp8": [P, I64, P, P, P, P, I64, I64, I64, I64, P, P],
     "ld_quantize_mxfp8": [P, I64, P, I64, P, I64, I64, I64, P],
-    "ld_gemm_mxfp8": [P, I64, P, P, P, P, I64, I64, I64, I64, P, P],
+    "ld_layernorm_mxfp8": [P, I64, P, P, P, I64, P, I64, I64, I64, c_float, P, I64, I64, I64, I64, I64, I64, I64, P],
+    "ld_gemm_mxfp8": [P, I64, P, P, P, P, I64, P, I64, I64, I64, I64, P, P],
     "ld_feature_norm_cl": [P, I32, P, P, P, I64, I64, I64, P],
     "ld_vq_nearest": [P, I64, P, P, I64, I64, I64, P],
     "ld_llm_decode_forward": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,

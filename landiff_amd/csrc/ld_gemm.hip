@@ -58,6 +58,8 @@ struct GemmParams {
   // MXFP8 form: one E8M0 scale byte per 32 consecutive K elements, [rows][K / 32]
   const unsigned char* mx_a;
   const unsigned char* mx_w;
+  unsigned char* mx_out;            // non-null: the output itself is MXFP8 (out = e4m3 bytes, ldo in bytes; scales here)
+  long ld_mx_out;
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
@@ -162,7 +164,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, float (&v)[
 // than the instruction cache, so each tile paid tens of microseconds of instruction fetch.  The three epilogues of
 // the DiT layer are therefore compile-time specialisations (a few KB each, fully unrolled, operands of a row-block
 // requested before its accumulators are staged); everything else takes the compact generic path.
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE = 2, EPI_GENERIC = 3 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE = 2, EPI_GENERIC = 3, EPI_GELU_MX = 4 };   // 4: bias + GELU, MXFP8 output
 
 template <int MI, int NI, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], char* smem, int wave, int lane,
@@ -254,7 +256,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float x = rbf(v[e] + bias[e]);                  // bf16 Linear output
-          if constexpr (EPI == EPI_GELU) x = act_gelu_tanh(x);
+          if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_MX) x = act_gelu_tanh(x);
           if constexpr (EPI == EPI_GATE) {
             x = rbf(x * ((e & 1) ? bf_hi(g[ps][e >> 1]) : bf_lo(g[ps][e >> 1])));
             x = rbf(((e & 1) ? bf_hi(rs[ps][e >> 1]) : bf_lo(rs[ps][e >> 1])) + x);
@@ -262,7 +264,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
           }
           v[e] = x;
         }
-        if (gm < p.M && col_ok) {
+        if constexpr (EPI == EPI_GELU_MX) {
+          // the bf16 activation, quantised where it is produced: a 32-column MX block is the 8 columns of four adjacent
+          // lanes of the same row (lane bits 0-1); scale = smallest power of two >= amax / 448 (ld_quant_mxfp8_kernel)
+          float amax = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] = rbf(v[e]); amax = fmaxf(amax, fabsf(v[e])); }
+          amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+          amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+          const uint32_t tb = __float_as_uint(amax * (1.0f / 448.0f));
+          int sb = (int)((tb >> 23) & 0xffu) + ((tb & 0x7fffffu) != 0u ? 1 : 0);
+          sb = amax > 0.f ? (sb < 1 ? 1 : (sb > 254 ? 254 : sb)) : 0;
+          const float inv = __uint_as_float((uint32_t)(254 - sb) << 23);
+          if (gm < p.M && col_ok) {
+            u32x2_t o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              unsigned w = 0;
+              w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * h] * inv, -448.f), 448.f), fminf(fmaxf(v[4 * h + 1] * inv, -448.f), 448.f), w, false);
+              w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * h + 2] * inv, -448.f), 448.f), fminf(fmaxf(v[4 * h + 3] * inv, -448.f), 448.f), w, true);
+              o[h] = w;
+            }
+            *(u32x2_t*)((unsigned char*)p.out + (long)gm * p.ldo + gn0) = o;
+            if ((lane & 3) == 0) p.mx_out[(long)gm * p.ld_mx_out + (gn0 >> 5)] = (unsigned char)sb;
+          }
+        } else if (gm < p.M && col_ok) {
           u32x4_t ow;
 #pragma unroll
           for (int e = 0; e < 4; ++e) ow[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
@@ -281,6 +307,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
 
 // which specialisation a problem may use (the generic path handles everything)
 inline int pick_epilogue(const GemmParams& p) {
+  if (p.mx_out) return EPI_GELU_MX;      // (the launcher checked: bias + GELU-tanh only, N % 32 == 0)
   const bool aligned = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) && !p.out_f32 && !p.mul;
   if (!aligned) return EPI_GENERIC;
   if (p.gate && p.resid && !p.resid_f32 && p.act == 0 && (p.ldr & 7) == 0 && (!p.add2 || (p.ldadd & 7) == 0) &&
@@ -1319,6 +1346,7 @@ int launch_f8(const GemmParams& p, hipStream_t stream) {
       case EPI_BIAS: return launch_kernel<ld_gemm_f8_kernel<EPI_BIAS, true>>("ld_gemm_mxfp8", grid, block, SMEM, stream, p);
       case EPI_GELU: return launch_kernel<ld_gemm_f8_kernel<EPI_GELU, true>>("ld_gemm_mxfp8", grid, block, SMEM, stream, p);
       case EPI_GATE: return launch_kernel<ld_gemm_f8_kernel<EPI_GATE, true>>("ld_gemm_mxfp8", grid, block, SMEM, stream, p);
+      case EPI_GELU_MX: return launch_kernel<ld_gemm_f8_kernel<EPI_GELU_MX, true>>("ld_gemm_mxfp8", grid, block, SMEM, stream, p);
       default: return launch_kernel<ld_gemm_f8_kernel<EPI_GENERIC, true>>("ld_gemm_mxfp8", grid, block, SMEM, stream, p);
     }
   }
@@ -1482,7 +1510,8 @@ LD_API int ld_quantize_mxfp8(const void* x, int64_t ldx, void* q, int64_t ldq, v
 }
 
 LD_API int ld_gemm_mxfp8(const void* A8, int64_t lda, const void* scales_a, const void* W8, const void* scales_w, void* out,
-                         int64_t ldo, int64_t M, int64_t N, int64_t K, const ld_epilogue_t* epi, void* stream) {
+                         int64_t ldo, void* out_scales, int64_t ldos, int64_t M, int64_t N, int64_t K,
+                         const ld_epilogue_t* epi, void* stream) {
   LD_REQUIRE(A8 && W8 && out && scales_a && scales_w, "ld_gemm_mxfp8: null pointer");
   LD_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0, "ld_gemm_mxfp8: K=%ld must be a positive multiple of 128", (long)K);
   LD_REQUIRE(lda % 16 == 0 && ((uintptr_t)A8 & 15) == 0 && ((uintptr_t)W8 & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
@@ -1495,5 +1524,11 @@ LD_API int ld_gemm_mxfp8(const void* A8, int64_t lda, const void* scales_a, cons
   p.group_m = 8;
   int rc = fill_epilogue(p, epi);
   if (rc) return rc;
+  if (out_scales) {     // MXFP8 output (the 4h activation handed to the next MXFP8 GEMM): bias + GELU-tanh only
+    LD_REQUIRE(N % 32 == 0 && ldo % 8 == 0 && ldos >= N / 32, "ld_gemm_mxfp8: MXFP8 output needs N %% 32 == 0, ldo %% 8 == 0");
+    LD_REQUIRE(p.act == LD_ACT_GELU_TANH && !p.resid && !p.gate && !p.add2 && !p.mul && !p.out_f32,
+               "ld_gemm_mxfp8: MXFP8 output is the bias + GELU-tanh epilogue only");
+    p.mx_out = (unsigned char*)out_scales; p.ld_mx_out = ldos;
+  }
   return launch_f8(p, (hipStream_t)stream);
 }

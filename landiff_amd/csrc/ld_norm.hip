@@ -112,6 +112,114 @@ __global__ __launch_bounds__(256) void ld_layernorm_kernel(LnParams p) {
   }
 }
 
+// LayerNorm (+ modulate) with MXFP8 output: the activation of the next MXFP8 GEMM is quantised where it is produced.
+template <int NC>   // chunks (of 8 elements) per lane
+__global__ __launch_bounds__(256) void ld_layernorm_mx_kernel(LnParams p, unsigned char* mxs, long lds) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.rows) return;
+  const int nchunk = p.D >> 3;
+  float v[NC][8];
+  float yv[NC][8], amaxv[NC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      if (p.x_f32) {
+        const float* xr = (const float*)p.x + (long)r * p.ldx + c * 8;
+        const f32x4_t a = *(const f32x4_t*)xr, b4 = *(const f32x4_t*)(xr + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = b4[e]; }
+      } else {
+        const u32x4_t a = *(const u32x4_t*)((const bf16_t*)p.x + (long)r * p.ldx + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][2 * e] = bf_lo(a[e]); v[i][2 * e + 1] = bf_hi(a[e]); }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)p.D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    if (lane + 64 * i < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)p.D + p.eps);
+  const bf16_t* shift = nullptr; const bf16_t* scale = nullptr;
+  if (p.mod) {
+    const int bb = r / p.rows_per_batch;
+    const bool txt = (r - bb * p.rows_per_batch) < p.text_len;
+    shift = p.mod + bb * p.mod_bstride + (txt ? p.shift_txt : p.shift_img);
+    scale = p.mod + bb * p.mod_bstride + (txt ? p.scale_txt : p.scale_img);
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    amaxv[i] = 0.f;
+    if (c >= nchunk) continue;
+    float y[8];
+    float wv[8], bv[8];
+    if (p.w) {
+      const u32x4_t ww = *(const u32x4_t*)(p.w + c * 8), bw = *(const u32x4_t*)(p.b + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { wv[2 * e] = bf_lo(ww[e]); wv[2 * e + 1] = bf_hi(ww[e]); bv[2 * e] = bf_lo(bw[e]); bv[2 * e + 1] = bf_hi(bw[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (v[i][e] - mean) * rstd;
+      if (p.w) t = t * wv[e] + bv[e];
+      y[e] = t;
+    }
+    if (shift) {
+      const u32x4_t sh = *(const u32x4_t*)(shift + c * 8), sc = *(const u32x4_t*)(scale + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // modulate(): x * (1 + scale) + shift, every op in bf16 as in the reference
+        const float s0 = rbf(1.0f + bf_lo(sc[e])), s1 = rbf(1.0f + bf_hi(sc[e]));
+        y[2 * e] = rbf(rbf(rbf(y[2 * e]) * s0) + bf_lo(sh[e]));
+        y[2 * e + 1] = rbf(rbf(rbf(y[2 * e + 1]) * s1) + bf_hi(sh[e]));
+      }
+    }
+    // MXFP8 output: the bf16 value the plain kernel would store, quantised in place.  A 32-element block is the chunks of
+    // four adjacent lanes (c = lane + 64 i); scale = smallest power of two >= amax / 448, as in ld_quant_mxfp8_kernel.
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { y[e] = rbf(y[e]); amax = fmaxf(amax, fabsf(y[e])); }
+    amaxv[i] = amax;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) yv[i][e] = y[e];
+  }
+  // (second pass: the shuffles must be executed by all 64 lanes, including those past the row's last chunk)
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    float amax = c < nchunk ? amaxv[i] : 0.f;
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    if (c >= nchunk) continue;
+    const uint32_t tb = __float_as_uint(amax * (1.0f / 448.0f));
+    int sb = (int)((tb >> 23) & 0xffu) + ((tb & 0x7fffffu) != 0u ? 1 : 0);
+    sb = amax > 0.f ? (sb < 1 ? 1 : (sb > 254 ? 254 : sb)) : 0;
+    const float inv = __uint_as_float((uint32_t)(254 - sb) << 23);
+    u32x2_t o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned w = 0;
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(yv[i][4 * h] * inv, -448.f), 448.f), fminf(fmaxf(yv[i][4 * h + 1] * inv, -448.f), 448.f), w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(yv[i][4 * h + 2] * inv, -448.f), 448.f), fminf(fmaxf(yv[i][4 * h + 3] * inv, -448.f), 448.f), w, true);
+      o[h] = w;
+    }
+    *(u32x2_t*)((unsigned char*)p.out + (long)r * p.ldo + c * 8) = o;
+    if ((c & 3) == 0) mxs[(long)r * lds + (c >> 2)] = (unsigned char)sb;
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // qkv [B*N][3*H*64] (thirds q|k|v) -> Q,K [B][H][Npad][64] and V^T [B][H][64][Npad].
 // mode 0: per-head LayerNorm(64) on q and k (DiT);  mode 1: interleaved-pair RoPE with a [N][32] table (TiTok).
@@ -408,4 +516,28 @@ LD_API int ld_groupnorm_apply(const void* x, void* out_padded, const double* sta
   dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
   hipLaunchKernelGGL(ld_gn_apply_kernel, grid, block, 0, (hipStream_t)stream, p);
   return ld_check_launch("ld_groupnorm_apply");
+}
+
+LD_API int ld_layernorm_mxfp8(const void* x, int64_t ldx, const void* w, const void* b, void* q, int64_t ldq, void* scales,
+                              int64_t lds, int64_t rows, int64_t D, float eps, const void* mod, int64_t mod_bstride,
+                              int64_t shift_img, int64_t scale_img, int64_t shift_txt, int64_t scale_txt,
+                              int64_t rows_per_batch, int64_t text_len, void* stream) {
+  LD_REQUIRE(x && q && scales, "ld_layernorm_mxfp8: null pointer");
+  LD_REQUIRE(D % 32 == 0 && D <= 2048 && D > 0 && ldq % 8 == 0 && lds >= D / 32, "ld_layernorm_mxfp8: D=%ld must be a multiple of 32 and <= 2048", (long)D);
+  LD_REQUIRE((w == nullptr) == (b == nullptr), "ld_layernorm_mxfp8: weight and bias go together");
+  LnParams p{};
+  p.x = x; p.out = q; p.w = (const bf16_t*)w; p.b = (const bf16_t*)b; p.mod = (const bf16_t*)mod;
+  p.ldx = ldx; p.ldo = ldq; p.rows = (int)rows; p.D = (int)D; p.eps = eps; p.x_f32 = 0; p.out_f32 = 0;
+  p.rows_per_batch = rows_per_batch > 0 ? (int)rows_per_batch : (1 << 30); p.text_len = (int)text_len;
+  p.mod_bstride = mod_bstride; p.shift_img = shift_img; p.scale_img = scale_img; p.shift_txt = shift_txt; p.scale_txt = scale_txt;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nc = (int)((D / 8 + 63) / 64);
+  switch (nc) {
+    case 1: hipLaunchKernelGGL(ld_layernorm_mx_kernel<1>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;
+    case 2: hipLaunchKernelGGL(ld_layernorm_mx_kernel<2>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;
+    case 3: hipLaunchKernelGGL(ld_layernorm_mx_kernel<3>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;
+    default: hipLaunchKernelGGL(ld_layernorm_mx_kernel<4>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;
+  }
+  return ld_check_launch("ld_layernorm_mxfp8");
 }

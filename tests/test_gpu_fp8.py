@@ -154,3 +154,35 @@ def test_mxfp8_chain_vs_bf16_gemm(cuda):
     rel_row = ((ops.gemm_fp8(q8, s8, v8, t8).float() - out16).norm() / out16.norm()).item()
     assert rel_mx < 0.05, rel_mx
     assert rel_mx < 1.25 * rel_row, (rel_mx, rel_row)                # e4m3 is floating point: both sit at its ~2^-4 relative step
+
+
+def test_fused_mxfp8_producers(cuda):
+    """The two fused producers equal the two-pass form bit for bit: LayerNorm+modulate -> MXFP8 == ld_layernorm then
+    ld_quantize_mxfp8, and the GELU epilogue with MXFP8 output == bf16 epilogue then ld_quantize_mxfp8."""
+    from landiff_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, N, D, T = 2, 300, 1920, 26
+    x = torch.randn(B * N, D, generator=g).to(cuda, BF)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(cuda, BF)
+    b = (0.1 * torch.randn(D, generator=g)).to(cuda, BF)
+    mod = (0.3 * torch.randn(B, 12 * D, generator=g)).to(cuda, BF)
+    kw = dict(mod=mod, mod_bstride=12 * D, shift_img=0, scale_img=D, shift_txt=6 * D, scale_txt=7 * D, rows_per_batch=N, text_len=T)
+    ln = torch.empty_like(x)
+    ops.layernorm(x, w, b, ln, 1e-5, **kw)
+    q2, s2 = ops.quantize_mxfp8(ln)
+    q1 = torch.empty(B * N, D, device=cuda, dtype=torch.uint8)
+    s1 = torch.empty(B * N, D // 32, device=cuda, dtype=torch.uint8)
+    ops.layernorm_mxfp8(x, w, b, q1, s1, 1e-5, **kw)
+    assert torch.equal(q1, q2) and torch.equal(s1, s2)
+    # GELU epilogue -> MXFP8
+    M, Nn, K = 700, 7680, 1920
+    a = torch.randn(M, K, generator=g).to(cuda, BF)
+    wt = (torch.randn(Nn, K, generator=g) / K ** 0.5).to(cuda, BF)
+    bias = torch.randn(Nn, generator=g).to(cuda, BF)
+    a8, sa = ops.quantize_mxfp8(a); w8, sw = ops.quantize_mxfp8(wt)
+    h = ops.gemm_mxfp8(a8, sa, w8, sw, bias=bias, act="gelu_tanh")
+    hq2, hs2 = ops.quantize_mxfp8(h)
+    hq1 = torch.empty(M, Nn, device=cuda, dtype=torch.uint8)
+    hs1 = torch.empty(M, Nn // 32, device=cuda, dtype=torch.uint8)
+    ops.gemm_mxfp8(a8, sa, w8, sw, out=hq1, out_scales=hs1, bias=bias, act="gelu_tanh")
+    assert torch.equal(hs1, hs2) and torch.equal(hq1, hq2)
