@@ -86,9 +86,10 @@ def main():
     ap.add_argument("--stream-chunks", type=int, default=0,
                     help="BASELINE config 3 instead of the headline config: N-chunk streaming long video (prefix 7 latent "
                          "frames pinned per later chunk, LLM KV / latents / VAE conv caches reused in HBM)")
-    ap.add_argument("--fp8-gemm", action="store_true",
+    ap.add_argument("--fp8-gemm", nargs="?", const="mx", default=None, choices=["mx", "row"],
                     help="BASELINE configs[4] only (with --stream-chunks): e4m3 operands for the DiT's qkv / dense / 4h / 4h->h "
-                         "linears.  Reduced precision: not the headline metric, reported under its own workload name and dtype")
+                         "linears -- mx (default): MXFP8 block scales, quantisation fused into LayerNorm / GELU epilogue; row: "
+                         "per-row scales with quantise passes.  Reduced precision: not the headline metric, own workload name and dtype")
     args = ap.parse_args()
     if args.fp8_gemm and not args.stream_chunks:
         raise SystemExit("--fp8-gemm belongs to the streaming long-video configuration (BASELINE configs[4]): add --stream-chunks N")
@@ -165,14 +166,14 @@ def main():
             "metric": METRIC, "value": world * n_frames * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if not args.fp8_gemm else "bf16 with fp8-e4m3 DiT linears (configs[4], not the headline precision)",
+            "dtype": "bf16" if not args.fp8_gemm else f"bf16 with fp8-e4m3 ({args.fp8_gemm}) DiT linears (configs[4], not the headline precision)",
             "data": "synthetic",
             "config": {"workload": ("tiny random-init plumbing config" if args.tiny else
                                     "LanDiff 5B full pipeline, single prompt per GPU, 49f 480x720, 50 sampler steps "
                                     "(VPSDE DPM-Solver++(2M), DynamicCFG), bf16, random-init weights at true shapes")
                                    + (f"; streaming long video: {stream} chunks, {prefix} prefix latent frames pinned per later "
                                       f"chunk, {n_frames} frames" if stream else "")
-                                   + ("; fp8 e4m3 MFMA for the DiT qkv/dense/4h/4h->h linears" if args.fp8_gemm else ""),
+                                   + (f"; fp8 e4m3 MFMA ({args.fp8_gemm} scaling) for the DiT qkv/dense/4h/4h->h linears" if args.fp8_gemm else ""),
                        "frames": n_frames, "height": 8 * d.latent_h, "width": 8 * d.latent_w,
                        "sampler_steps": cfg.sampler.num_steps, "llm_steps": (1244 if not stream else None) if not args.tiny else None,
                        "parallelism": f"dp{world} over prompts, RCCL all_gather of uint8 frames only"},

@@ -53,9 +53,10 @@ class _Branch:
             )
             if control:
                 lw["zero_w"] = g(a + f"zero_linears.{i}.weight")
-            if fp8_gemm:      # e4m3 weights, one scale per output channel; the bf16 copies of the four big matrices go
+            if fp8_gemm:      # e4m3 weights (one scale per output channel, or MX blocks of 32 along K); the bf16 copies go
+                quant = ops.quantize_mxfp8 if fp8_gemm == "mx" else ops.quantize_fp8
                 for name in ("qkv", "dense", "h4", "h1"):
-                    lw[name + "_w8"], lw[name + "_s"] = ops.quantize_fp8(lw.pop(name + "_w"))
+                    lw[name + "_w8"], lw[name + "_s"] = quant(lw.pop(name + "_w"))
             self.layers.append(lw)
         if not control:
             f = "mixins.final_layer."
@@ -71,9 +72,11 @@ class ControlDiTRunner:
     B = 2
 
     def __init__(self, main_sd: dict, control_sd: dict, cfg: DiTConfig, device, fp8_gemm: bool = False):
-        """fp8_gemm: BASELINE configs[4] -- the qkv / dense / 4h / 4h->h linears run on e4m3 operands (weights quantised
-        once per output channel, activations per row in front of each GEMM); attention, norms, residual stream and every
-        other layer stay bf16.  Off for the headline metric and for every parity claim of the bf16 path."""
+        """fp8_gemm: BASELINE configs[4] -- the qkv / dense / 4h / 4h->h linears run on e4m3 operands; attention, norms,
+        residual stream and every other layer stay bf16.  True / "row": weights quantised once per output channel,
+        activations per row by a pass in front of each GEMM.  "mx": MXFP8 (one power-of-two scale per 32 K elements, applied
+        by the MFMA); LayerNorm+modulate and the GELU epilogue write MXFP8 directly, only the attention output still takes
+        a quantise pass.  Off for the headline metric and for every parity claim of the bf16 path."""
         self.cfg, self.dev, self.fp8 = cfg, device, fp8_gemm
         self.main = _Branch(main_sd, cfg, False, device, fp8_gemm)
         self.ctrl = _Branch(control_sd, cfg, True, device, fp8_gemm)
@@ -106,6 +109,10 @@ class ControlDiTRunner:
         if fp8_gemm:
             self.a8 = torch.empty(M, 4 * d, device=device, dtype=torch.uint8)    # quantised GEMM input (largest K)
             self.sa = e(M, dt=torch.float32)
+        if fp8_gemm == "mx":
+            self.a8d = torch.empty(M, d, device=device, dtype=torch.uint8)        # MXFP8 activations of width d ...
+            self.s8d = torch.empty(M, d // 32, device=device, dtype=torch.uint8)
+            self.s8m = torch.empty(M, 4 * d // 32, device=device, dtype=torch.uint8)   # ... and 4d (codes in self.a8)
         self.sem = None                         # [T, C, H, W] bf16, set per video
         self.attn_events = None                 # bench.py: list of (start, end) HIP events around every attention launch
 
@@ -145,7 +152,42 @@ class ControlDiTRunner:
         ops.quantize_fp8(x, a8, self.sa)
         return ops.gemm_fp8(a8, self.sa, lw[name + "_w8"], lw[name + "_s"], out=out, bias=lw[name + "_b"], **epi)
 
+    def _attention(self):
+        c, N = self.cfg, self.N
+        if self.attn_events is not None:       # bench.py: HIP events around every attention launch (roofline.achieved)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5)
+            e1.record()
+            self.attn_events.append((e0, e1))
+        else:
+            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5)
+
+    def _layer_mx(self, br: _Branch, i: int, h_in: torch.Tensor, h_out: torch.Tensor, control_add=None):
+        """_layer with MXFP8 operands on the four large linears (fp8_gemm="mx")."""
+        c, lw = self.cfg, br.layers[i]
+        d, N = c.hidden, self.N
+        mod = dict(mod=self.ada, mod_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
+        gate = dict(gate=self.ada, gate_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
+        ops.gemv(self.emb, lw["ada_w"], self.ada, bias=lw["ada_b"], in_act="silu")
+        ops.layernorm_mxfp8(h_in, lw["ln1_w"], lw["ln1_b"], self.a8d, self.s8d, c.block_ln_eps, shift_img=0, scale_img=d,
+                            shift_txt=6 * d, scale_txt=7 * d, **mod)
+        ops.gemm_mxfp8(self.a8d, self.s8d, lw["qkv_w8"], lw["qkv_s"], out=self.qkv, bias=lw["qkv_b"])
+        ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
+        self._attention()
+        ops.quantize_mxfp8(self.attn.view(-1, d), self.a8d, self.s8d)
+        ops.gemm_mxfp8(self.a8d, self.s8d, lw["dense_w8"], lw["dense_s"], out=h_out, bias=lw["dense_b"], resid=h_in,
+                       gate_off_img=2 * d, gate_off_txt=8 * d, **gate)
+        ops.layernorm_mxfp8(h_out, lw["ln2_w"], lw["ln2_b"], self.a8d, self.s8d, c.block_ln_eps, shift_img=3 * d, scale_img=4 * d,
+                            shift_txt=9 * d, scale_txt=10 * d, **mod)
+        a8m = self.a8.view(self.M, 4 * d)
+        ops.gemm_mxfp8(self.a8d, self.s8d, lw["h4_w8"], lw["h4_s"], out=a8m, out_scales=self.s8m, bias=lw["h4_b"], act="gelu_tanh")
+        ops.gemm_mxfp8(a8m, self.s8m, lw["h1_w8"], lw["h1_s"], out=h_out, bias=lw["h1_b"], resid=h_out, gate_off_img=5 * d,
+                       gate_off_txt=11 * d, add2=control_add, **gate)
+
     def _layer(self, br: _Branch, i: int, h_in: torch.Tensor, h_out: torch.Tensor, control_add=None):
+        if self.fp8 == "mx":
+            return self._layer_mx(br, i, h_in, h_out, control_add)
         c, lw = self.cfg, br.layers[i]
         d, N = c.hidden, self.N
         mod = dict(mod=self.ada, mod_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
@@ -154,14 +196,7 @@ class ControlDiTRunner:
                       shift_txt=6 * d, scale_txt=7 * d, **mod)
         self._linear(self.ln, lw, "qkv", self.qkv)
         ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
-        if self.attn_events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5)
-            e1.record()
-            self.attn_events.append((e0, e1))
-        else:
-            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5)
+        self._attention()
         gate = dict(gate=self.ada, gate_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
         self._linear(self.attn.view(-1, d), lw, "dense", h_out, resid=h_in, gate_off_img=2 * d, gate_off_txt=8 * d, **gate)
         ops.layernorm(h_out, lw["ln2_w"], lw["ln2_b"], self.ln, c.block_ln_eps, shift_img=3 * d, scale_img=4 * d,

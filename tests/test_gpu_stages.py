@@ -70,14 +70,15 @@ def test_dit_fp8_linears_close_to_bf16(cuda, setup):
     ctx = torch.randn(1, d.text_len, d.text_dim, generator=g)
     sem = torch.randn(d.latent_frames, d.in_channels, d.latent_h, d.latent_w, generator=g).to(torch.bfloat16)
     outs = []
-    for fp8 in (False, True):
+    for fp8 in (False, "row", "mx"):
         run = ControlDiTRunner(st["dit_main"], st["dit_control"], d, cuda, fp8_gemm=fp8)
         run.set_condition(ctx, sem)
         out = torch.empty_like(x)
         run.step(x, 500, -0.7, 0.7, 1.0, out)           # scale 1: the cond branch alone (CFG would amplify the noise)
         outs.append(out.float().cpu())
-    rel = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()
-    assert 1e-5 < rel < 0.1, rel
+    for o in outs[1:]:
+        rel = ((o - outs[0]).norm() / outs[0].norm()).item()
+        assert 1e-5 < rel < 0.1, rel
 
 
 def test_sampler_loop_matches_oracle(cuda, setup):
