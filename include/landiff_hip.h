@@ -88,20 +88,21 @@ int ld_gemm_fp8(const void* A8, int64_t lda, const float* scale_a, const void* W
 
 /* MXFP8 form of the same (OCP Microscaling v1.0 container: blocks of 32 consecutive K elements share one E8M0 scale;
  * here the smallest power of two >= amax / 448, so nothing saturates; elements are e4m3 casts of x / scale).
- * scales: uint8 [rows][lds >= K/32] (byte = exponent + 127; 0 for an all-zero block). */
+ * scales: uint8, K-tile-major [K/128][lds >= rows][4] (byte = exponent + 127; 0 for an all-zero block): the 256 rows of
+ * a GEMM tile and K-tile are 1 KB contiguous for the LDS-DMA.  K % 128 == 0. */
 int ld_quantize_mxfp8(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds, int64_t rows,
                       int64_t K, void* stream);
 
 /* out = epilogue(sum over blocks of 2^(sa-127) 2^(sw-127) sum_{k in block} A8[m][k] W8[n][k]): the block scales are
- * applied by v_mfma_scale_f32_32x32x64_f8f6f4 itself.  scales_a [M][K/32], scales_w [N][K/32] contiguous. K % 128 == 0. */
+ * applied by v_mfma_scale_f32_32x32x64_f8f6f4 itself.  scales_a [K/128][M][4], scales_w [K/128][N][4] contiguous. */
 int ld_gemm_mxfp8(const void* A8, int64_t lda, const void* scales_a, const void* W8, const void* scales_w, void* out,
                   int64_t ldo, void* out_scales, int64_t ldos, int64_t M, int64_t N, int64_t K,
                   const ld_epilogue_t* epi, void* stream);
-/* (out_scales != NULL: the output is itself MXFP8 -- out = e4m3 [M][ldo bytes], out_scales [M][ldos >= N/32] -- for the
+/* (out_scales != NULL: the output is itself MXFP8 -- out = e4m3 [M][ldo bytes], out_scales [N/128][ldos >= M][4] -- for the
  * bias + GELU-tanh epilogue of dense_h_to_4h, whose result only feeds the next MXFP8 GEMM.) */
 
 /* ld_layernorm (+ AdaLN modulate) with MXFP8 output: exactly ld_layernorm's bf16 result, quantised where it is produced
- * (q e4m3 [rows][ldq bytes], scales [rows][lds >= D/32]) for the MXFP8 GEMM that consumes it.  bf16 input, D % 32 == 0. */
+ * (q e4m3 [rows][ldq bytes], scales [D/128][lds >= rows][4]) for the MXFP8 GEMM that consumes it.  bf16 input, D % 128 == 0. */
 int ld_layernorm_mxfp8(const void* x, int64_t ldx, const void* w, const void* b, void* q, int64_t ldq, void* scales,
                        int64_t lds, int64_t rows, int64_t D, float eps, const void* mod, int64_t mod_bstride,
                        int64_t shift_img, int64_t scale_img, int64_t shift_txt, int64_t scale_txt,

@@ -55,7 +55,8 @@ struct GemmParams {
   // fp8 (e4m3) operands: A and W are byte matrices (lda in bytes), dequantised by per-row / per-output-channel scales
   const float* scale_a;             // [M]
   const float* scale_w;             // [N]
-  // MXFP8 form: one E8M0 scale byte per 32 consecutive K elements, [rows][K / 32]
+  // MXFP8 form: one E8M0 scale byte per 32 consecutive K elements, stored K-tile-major [K / 128][rows][4] so that the 256
+  // rows of a tile and K-tile are 1 KB contiguous (a [rows][K / 32] strip cost one cache line per row and K-tile)
   const unsigned char* mx_a;
   const unsigned char* mx_w;
   unsigned char* mx_out;            // non-null: the output itself is MXFP8 (out = e4m3 bytes, ldo in bytes; scales here)
@@ -269,24 +270,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
           // lanes of the same row (lane bits 0-1); scale = smallest power of two >= amax / 448 (ld_quant_mxfp8_kernel)
           float amax = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { v[e] = rbf(v[e]); amax = fmaxf(amax, fabsf(v[e])); }
+          for (int e = 0; e < 4; ++e) {       // round to bf16 pairwise (one cvt_pk + two unpacks per pair)
+            const uint32_t pk = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            v[2 * e] = bf_lo(pk); v[2 * e + 1] = bf_hi(pk);
+            amax = fmaxf(amax, fmaxf(fabsf(v[2 * e]), fabsf(v[2 * e + 1])));
+          }
           amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
           amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
           const uint32_t tb = __float_as_uint(amax * (1.0f / 448.0f));
           int sb = (int)((tb >> 23) & 0xffu) + ((tb & 0x7fffffu) != 0u ? 1 : 0);
           sb = amax > 0.f ? (sb < 1 ? 1 : (sb > 254 ? 254 : sb)) : 0;
-          const float inv = __uint_as_float((uint32_t)(254 - sb) << 23);
+          const float inv = __uint_as_float((uint32_t)(254 - sb) << 23);      // exact power of two: |v| * inv <= 448, no clamp
           if (gm < p.M && col_ok) {
             u32x2_t o;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               unsigned w = 0;
-              w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * h] * inv, -448.f), 448.f), fminf(fmaxf(v[4 * h + 1] * inv, -448.f), 448.f), w, false);
-              w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * h + 2] * inv, -448.f), 448.f), fminf(fmaxf(v[4 * h + 3] * inv, -448.f), 448.f), w, true);
+              w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * h] * inv, v[4 * h + 1] * inv, w, false);
+              w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * h + 2] * inv, v[4 * h + 3] * inv, w, true);
               o[h] = w;
             }
             *(u32x2_t*)((unsigned char*)p.out + (long)gm * p.ldo + gn0) = o;
-            if ((lane & 3) == 0) p.mx_out[(long)gm * p.ld_mx_out + (gn0 >> 5)] = (unsigned char)sb;
+            if ((lane & 3) == 0) p.mx_out[(((long)(gn0 >> 7)) * p.ld_mx_out + gm) * 4 + ((gn0 >> 5) & 3)] = (unsigned char)sb;
           }
         } else if (gm < p.M && col_ok) {
           u32x4_t ow;
@@ -544,16 +549,18 @@ __global__ __launch_bounds__(512, 2) void ld_gemm_f8_kernel(GemmParams p) {
   // MX scales: one dword (4 blocks = one K-tile) per tile row, staged through LDS next to the operands -- waves 0-3 fetch
   // the 256 A rows' dwords, waves 4-7 the 256 W rows' (one 4-byte LDS-DMA each) -- and read back at use (no registers held)
   constexpr int SC_OFF = 2 * STAGE;                          // [2 stages][A 1 KB | W 1 KB]
-  const int kb = p.K >> 5;
+  const long srows = wave < 4 ? p.M : p.N;                    // rows per K-tile slab of the scale array
+  const long sorig = wave < 4 ? m0 : n0;
   const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(MX ? (wave < 4 ? p.mx_a + (long)m0 * kb : p.mx_w + (long)n0 * kb) : (const unsigned char*)p.A), 0,
-      MX ? clip((long)((wave < 4 ? p.M - m0 : p.N - n0)) * kb) : 0, 0x00020000);
-  const uint32_t soff = (uint32_t)(((wave & 3) * 64 + lane) * kb);
+      (void*)(MX ? (wave < 4 ? p.mx_a : p.mx_w) + sorig * 4 : (const unsigned char*)p.A), 0,
+      MX ? clip(((long)(p.K >> 7) * srows - sorig) * 4) : 0, 0x00020000);
+  const uint32_t soff = (uint32_t)(((wave & 3) * 64 + lane) * 4);
+  const int sslab = (int)(srows * 4);                         // bytes between consecutive K-tiles' slabs
   auto stage = [&](auto bufc, int kt) {
     constexpr int buf = decltype(bufc)::value;
     if (MX) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)(smem + SC_OFF + buf * 2048 + wave * 256),
-                                               4, soff, kt * 4, 0, 0);
+                                               4, soff, kt * sslab, 0, 0);
     }
     char* base = smem + buf * STAGE;
 #pragma unroll
@@ -1387,12 +1394,12 @@ __global__ __launch_bounds__(256) void ld_quant_mxfp8_kernel(const bf16_t* x, lo
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         unsigned w = 0;
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(f[4 * h] * inv, -448.f), 448.f), fminf(fmaxf(f[4 * h + 1] * inv, -448.f), 448.f), w, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(f[4 * h + 2] * inv, -448.f), 448.f), fminf(fmaxf(f[4 * h + 3] * inv, -448.f), 448.f), w, true);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * h] * inv, f[4 * h + 1] * inv, w, false);       // |f| * inv <= 448 by construction
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * h + 2] * inv, f[4 * h + 3] * inv, w, true);
         o[h] = w;
       }
       *(u32x2_t*)(q + (long)r * ldq + c * 8) = o;
-      if ((c & 3) == 0) sc[(long)r * lds + (c >> 2)] = (unsigned char)sb;
+      if ((c & 3) == 0) sc[((long)(c >> 4) * lds + r) * 4 + ((c >> 2) & 3)] = (unsigned char)sb;   // [K/128][lds rows][4]
     }
   }
 }
@@ -1503,7 +1510,7 @@ LD_API int ld_gemm_fp8(const void* A8, int64_t lda, const float* scale_a, const 
 LD_API int ld_quantize_mxfp8(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds, int64_t rows,
                              int64_t K, void* stream) {
   LD_REQUIRE(x && q && scales && rows > 0, "ld_quantize_mxfp8: bad args");
-  LD_REQUIRE(K % 32 == 0 && ldx % 8 == 0 && ldq % 8 == 0 && lds >= K / 32, "ld_quantize_mxfp8: K=%ld must be a multiple of 32", (long)K);
+  LD_REQUIRE(K % 128 == 0 && ldx % 8 == 0 && ldq % 8 == 0 && lds >= rows, "ld_quantize_mxfp8: K=%ld must be a multiple of 128, lds >= rows", (long)K);
   hipLaunchKernelGGL(ld_quant_mxfp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (long)ldx, (unsigned char*)q, (long)ldq, (unsigned char*)scales, (long)lds, (int)rows, (int)K);
   return ld_check_launch("ld_quantize_mxfp8");
@@ -1520,12 +1527,12 @@ LD_API int ld_gemm_mxfp8(const void* A8, int64_t lda, const void* scales_a, cons
   GemmParams p{};
   p.A = (const bf16_t*)A8; p.W = (const bf16_t*)W8; p.out = out;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = lda; p.ldo = ldo;
-  p.mx_a = (const unsigned char*)scales_a; p.mx_w = (const unsigned char*)scales_w;      // [M][K/32], [N][K/32] contiguous
+  p.mx_a = (const unsigned char*)scales_a; p.mx_w = (const unsigned char*)scales_w;      // [K/128][M][4], [K/128][N][4] contiguous
   p.group_m = 8;
   int rc = fill_epilogue(p, epi);
   if (rc) return rc;
   if (out_scales) {     // MXFP8 output (the 4h activation handed to the next MXFP8 GEMM): bias + GELU-tanh only
-    LD_REQUIRE(N % 32 == 0 && ldo % 8 == 0 && ldos >= N / 32, "ld_gemm_mxfp8: MXFP8 output needs N %% 32 == 0, ldo %% 8 == 0");
+    LD_REQUIRE(N % 128 == 0 && ldo % 8 == 0 && ldos >= M, "ld_gemm_mxfp8: MXFP8 output needs N %% 128 == 0, ldo %% 8 == 0, ldos >= M");
     LD_REQUIRE(p.act == LD_ACT_GELU_TANH && !p.resid && !p.gate && !p.add2 && !p.mul && !p.out_f32,
                "ld_gemm_mxfp8: MXFP8 output is the bias + GELU-tanh epilogue only");
     p.mx_out = (unsigned char*)out_scales; p.ld_mx_out = ldos;

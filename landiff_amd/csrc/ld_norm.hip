@@ -210,12 +210,12 @@ __global__ __launch_bounds__(256) void ld_layernorm_mx_kernel(LnParams p, unsign
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       unsigned w = 0;
-      w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(yv[i][4 * h] * inv, -448.f), 448.f), fminf(fmaxf(yv[i][4 * h + 1] * inv, -448.f), 448.f), w, false);
-      w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(yv[i][4 * h + 2] * inv, -448.f), 448.f), fminf(fmaxf(yv[i][4 * h + 3] * inv, -448.f), 448.f), w, true);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(yv[i][4 * h] * inv, yv[i][4 * h + 1] * inv, w, false);     // <= 448 by construction
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(yv[i][4 * h + 2] * inv, yv[i][4 * h + 3] * inv, w, true);
       o[h] = w;
     }
     *(u32x2_t*)((unsigned char*)p.out + (long)r * p.ldo + c * 8) = o;
-    if ((c & 3) == 0) mxs[(long)r * lds + (c >> 2)] = (unsigned char)sb;
+    if ((c & 3) == 0) mxs[((long)(c >> 4) * lds + r) * 4 + ((c >> 2) & 3)] = (unsigned char)sb;   // [D/128][lds rows][4]
   }
 }
 
@@ -523,7 +523,7 @@ LD_API int ld_layernorm_mxfp8(const void* x, int64_t ldx, const void* w, const v
                               int64_t shift_img, int64_t scale_img, int64_t shift_txt, int64_t scale_txt,
                               int64_t rows_per_batch, int64_t text_len, void* stream) {
   LD_REQUIRE(x && q && scales, "ld_layernorm_mxfp8: null pointer");
-  LD_REQUIRE(D % 32 == 0 && D <= 2048 && D > 0 && ldq % 8 == 0 && lds >= D / 32, "ld_layernorm_mxfp8: D=%ld must be a multiple of 32 and <= 2048", (long)D);
+  LD_REQUIRE(D % 128 == 0 && D <= 2048 && D > 0 && ldq % 8 == 0 && lds >= rows, "ld_layernorm_mxfp8: D=%ld must be a multiple of 128 and <= 2048, lds >= rows", (long)D);
   LD_REQUIRE((w == nullptr) == (b == nullptr), "ld_layernorm_mxfp8: weight and bias go together");
   LnParams p{};
   p.x = x; p.out = q; p.w = (const bf16_t*)w; p.b = (const bf16_t*)b; p.mod = (const bf16_t*)mod;

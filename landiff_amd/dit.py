@@ -111,8 +111,8 @@ class ControlDiTRunner:
             self.sa = e(M, dt=torch.float32)
         if fp8_gemm == "mx":
             self.a8d = torch.empty(M, d, device=device, dtype=torch.uint8)        # MXFP8 activations of width d ...
-            self.s8d = torch.empty(M, d // 32, device=device, dtype=torch.uint8)
-            self.s8m = torch.empty(M, 4 * d // 32, device=device, dtype=torch.uint8)   # ... and 4d (codes in self.a8)
+            self.s8d = torch.empty(d // 128, M, 4, device=device, dtype=torch.uint8)       # scales, K-tile-major
+            self.s8m = torch.empty(4 * d // 128, M, 4, device=device, dtype=torch.uint8)   # ... and 4d (codes in self.a8)
         self.sem = None                         # [T, C, H, W] bf16, set per video
         self.attn_events = None                 # bench.py: list of (start, end) HIP events around every attention launch
 

@@ -119,17 +119,17 @@ def gemm_fp8(a8: torch.Tensor, scale_a: torch.Tensor, w8: torch.Tensor, scale_w:
 
 
 def quantize_mxfp8(x: torch.Tensor, q: torch.Tensor | None = None, scales: torch.Tensor | None = None):
-    """MXFP8 quantisation: x bf16 [M,K] -> (q uint8 [M,K] e4m3 codes, scales uint8 [M,K/32] E8M0 bytes)."""
+    """MXFP8 quantisation: x bf16 [M,K] -> (q uint8 [M,K] e4m3 codes, scales uint8 [K/128, M, 4] E8M0 bytes, K-tile-major)."""
     _bf16(x, "x")
     M, K = x.shape
-    assert x.stride(1) == 1 and K % 32 == 0
+    assert x.stride(1) == 1 and K % 128 == 0
     if q is None:
         q = torch.empty(M, K, device=x.device, dtype=torch.uint8)
     if scales is None:
-        scales = torch.empty(M, K // 32, device=x.device, dtype=torch.uint8)
+        scales = torch.empty(K // 128, M, 4, device=x.device, dtype=torch.uint8)
     assert q.dtype == torch.uint8 and q.shape == (M, K) and q.stride(1) == 1
-    assert scales.dtype == torch.uint8 and scales.shape == (M, K // 32) and scales.stride(1) == 1
-    check(_lib.load().ld_quantize_mxfp8(_ptr(x), x.stride(0), _ptr(q), q.stride(0), _ptr(scales), scales.stride(0), M, K,
+    assert scales.dtype == torch.uint8 and tuple(scales.shape) == (K // 128, M, 4) and scales.is_contiguous()
+    check(_lib.load().ld_quantize_mxfp8(_ptr(x), x.stride(0), _ptr(q), q.stride(0), _ptr(scales), M, M, K,
                                         _stream()), "ld_quantize_mxfp8")
     return q, scales
 
@@ -137,23 +137,23 @@ def quantize_mxfp8(x: torch.Tensor, q: torch.Tensor | None = None, scales: torch
 def gemm_mxfp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, out: torch.Tensor | None = None,
                out_scales: torch.Tensor | None = None, **epi) -> torch.Tensor:
     """out[M,N] = epilogue(dequant(a8, sa) @ dequant(w8, sw)^T) with the MX block scales applied inside the MFMA.
-    out_scales (uint8 [M, N/32]): the output is MXFP8 too (out uint8 [M,N]); bias + act="gelu_tanh" only."""
+    out_scales (uint8 [N/128, M, 4]): the output is MXFP8 too (out uint8 [M,N]); bias + act="gelu_tanh" only."""
     assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(1) == 1 and w8.is_contiguous()
     M, K = a8.shape
     N = w8.shape[0]
-    assert w8.shape[1] == K and tuple(sa.shape) == (M, K // 32) and tuple(sw.shape) == (N, K // 32)
+    assert w8.shape[1] == K and tuple(sa.shape) == (K // 128, M, 4) and tuple(sw.shape) == (K // 128, N, 4)
     assert sa.dtype == torch.uint8 and sw.dtype == torch.uint8 and sa.is_contiguous() and sw.is_contiguous()
     out_f32 = bool(epi.get("out_f32", False))
     if out_scales is not None:
         assert out is not None and out.dtype == torch.uint8 and out_scales.dtype == torch.uint8
-        assert tuple(out_scales.shape) == (M, N // 32) and out_scales.stride(1) == 1
+        assert tuple(out_scales.shape) == (N // 128, M, 4) and out_scales.is_contiguous()
     elif out is None:
         out = torch.empty((M, N), device=a8.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     assert out.stride(1) == 1 and out.shape == (M, N)
     assert out_scales is not None or (out.dtype == torch.float32) == out_f32
     e = make_epilogue(**epi)
     check(_lib.load().ld_gemm_mxfp8(_ptr(a8), a8.stride(0), _ptr(sa), _ptr(w8), _ptr(sw), _ptr(out), out.stride(0),
-                                    _ptr(out_scales), out_scales.stride(0) if out_scales is not None else 0,
+                                    _ptr(out_scales), M if out_scales is not None else 0,
                                     M, N, K, ctypes.byref(e), _stream()), "ld_gemm_mxfp8")
     return out
 
@@ -309,13 +309,13 @@ def layernorm(x, w, b, out, eps, *, mod=None, mod_bstride=0, shift_img=0, scale_
 
 def layernorm_mxfp8(x, w, b, q, scales, eps, *, mod=None, mod_bstride=0, shift_img=0, scale_img=0, shift_txt=0, scale_txt=0,
                     rows_per_batch=0, text_len=0):
-    """layernorm(...) whose bf16 result is written as MXFP8: q uint8 [rows, D], scales uint8 [rows, D/32]."""
+    """layernorm(...) whose bf16 result is written as MXFP8: q uint8 [rows, D], scales uint8 [D/128, rows, 4]."""
     _bf16(x, "x")
     rows, D = x.shape
     assert x.stride(1) == 1 and q.dtype == torch.uint8 and q.shape == (rows, D) and q.stride(1) == 1
-    assert scales.dtype == torch.uint8 and tuple(scales.shape) == (rows, D // 32) and scales.stride(1) == 1
+    assert scales.dtype == torch.uint8 and tuple(scales.shape) == (D // 128, rows, 4) and scales.is_contiguous()
     check(_lib.load().ld_layernorm_mxfp8(_ptr(x), x.stride(0), _ptr(w), _ptr(b), _ptr(q), q.stride(0), _ptr(scales),
-                                         scales.stride(0), rows, D, float(eps), _ptr(mod), mod_bstride, shift_img, scale_img,
+                                         rows, rows, D, float(eps), _ptr(mod), mod_bstride, shift_img, scale_img,
                                          shift_txt, scale_txt, rows_per_batch, text_len, _stream()), "ld_layernorm_mxfp8")
     return q, scales
 

@@ -94,6 +94,16 @@ def _mx_quant_ref(x):
     return q, sb.to(torch.uint8)
 
 
+def _tile_major(sb):
+    """[M, K/32] scale bytes -> the kernels' K-tile-major layout [K/128, M, 4]."""
+    M, nb = sb.shape
+    return sb.view(M, nb // 4, 4).permute(1, 0, 2).contiguous()
+
+
+def _row_major(st):
+    return st.permute(1, 0, 2).reshape(st.shape[1], -1)
+
+
 def _mx_deq(q, sb):
     M, K = q.shape
     return (q.view(F8).float().view(M, K // 32, 32) * torch.pow(2.0, sb.float() - 127)[..., None]).view(M, K)
@@ -105,11 +115,12 @@ def test_quantize_mxfp8(cuda, M, K):
     g = torch.Generator().manual_seed(M + K)
     x = (torch.randn(M, K, generator=g) * torch.logspace(-4, 3, K)[None, :]).to(BF)      # wildly different block magnitudes
     x[M // 2, 32:96] = 0
-    q, sb = ops.quantize_mxfp8(x.to(cuda))
+    q, st = ops.quantize_mxfp8(x.to(cuda))
+    sb = _row_major(st.cpu())
     wq, ws = _mx_quant_ref(x)
-    assert torch.equal(sb.cpu(), ws)
+    assert torch.equal(sb, ws)
     assert torch.equal(q.cpu(), wq)
-    rel = ((_mx_deq(q.cpu(), sb.cpu()) - x.float()).norm() / x.float().norm()).item()
+    rel = ((_mx_deq(q.cpu(), sb) - x.float()).norm() / x.float().norm()).item()
     assert rel < 0.05, rel
 
 
@@ -134,7 +145,7 @@ def test_gemm_mxfp8_exact_operands(cuda, M, N, K, form):
         res = torch.randn(M, N, generator=g).to(BF)
         kw["resid"] = res.to(cuda)
         post = lambda r: res.float() + r.float().to(BF).float()
-    out = ops.gemm_mxfp8(a8.to(cuda), sa.to(cuda), w8.to(cuda), sw.to(cuda), **kw)
+    out = ops.gemm_mxfp8(a8.to(cuda), _tile_major(sa).to(cuda), w8.to(cuda), _tile_major(sw).to(cuda), **kw)
     want = post(ref.float())
     err = (out.float().cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-6)
     assert err < 1e-2, err
@@ -171,7 +182,7 @@ def test_fused_mxfp8_producers(cuda):
     ops.layernorm(x, w, b, ln, 1e-5, **kw)
     q2, s2 = ops.quantize_mxfp8(ln)
     q1 = torch.empty(B * N, D, device=cuda, dtype=torch.uint8)
-    s1 = torch.empty(B * N, D // 32, device=cuda, dtype=torch.uint8)
+    s1 = torch.empty(D // 128, B * N, 4, device=cuda, dtype=torch.uint8)
     ops.layernorm_mxfp8(x, w, b, q1, s1, 1e-5, **kw)
     assert torch.equal(q1, q2) and torch.equal(s1, s2)
     # GELU epilogue -> MXFP8
@@ -183,6 +194,6 @@ def test_fused_mxfp8_producers(cuda):
     h = ops.gemm_mxfp8(a8, sa, w8, sw, bias=bias, act="gelu_tanh")
     hq2, hs2 = ops.quantize_mxfp8(h)
     hq1 = torch.empty(M, Nn, device=cuda, dtype=torch.uint8)
-    hs1 = torch.empty(M, Nn // 32, device=cuda, dtype=torch.uint8)
+    hs1 = torch.empty(Nn // 128, M, 4, device=cuda, dtype=torch.uint8)
     ops.gemm_mxfp8(a8, sa, w8, sw, out=hq1, out_scales=hs1, bias=bias, act="gelu_tanh")
     assert torch.equal(hs1, hs2) and torch.equal(hq1, hq2)

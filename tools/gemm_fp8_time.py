@@ -22,4 +22,8 @@ for name, N, K in (("qkv", 5760, 1920), ("proj", 1920, 1920), ("fc1", 7680, 1920
     t16 = t(lambda: ops.gemm(a, w, out=out, bias=bias))
     t8 = t(lambda: ops.gemm_fp8(a8, sa, w8, sw, out=out, bias=bias))
     tq = t(lambda: ops.quantize_fp8(a, a8, sa))
-    print(f"{name:5s} M={M} N={N} K={K}: bf16 {t16*1e3:7.1f} us ({fl/t16/1e9:6.0f} TF)   fp8 {t8*1e3:7.1f} us ({fl/t8/1e9:6.0f} TF)   quantise A {tq*1e3:6.1f} us")
+    m8, ms = ops.quantize_mxfp8(a); v8, vs = ops.quantize_mxfp8(w)
+    tm = t(lambda: ops.gemm_mxfp8(m8, ms, v8, vs, out=out, bias=bias))
+    tmq = t(lambda: ops.quantize_mxfp8(a, m8, ms))
+    print(f"{name:5s} M={M} N={N} K={K}: bf16 {t16*1e3:7.1f} us ({fl/t16/1e9:6.0f} TF)   fp8 row {t8*1e3:7.1f} us ({fl/t8/1e9:6.0f} TF) + quantise {tq*1e3:6.1f} us"
+          f"   MXFP8 {tm*1e3:7.1f} us ({fl/tm/1e9:6.0f} TF) + quantise {tmq*1e3:6.1f} us")
