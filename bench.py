@@ -22,6 +22,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 METRIC = "end-to-end frames/sec, 49f 480x720 @50 steps"
+# HBM bytes per attention launch at the headline shape from separate rocprofv3 --pmc passes
+# (profiles/r01c_attn_pipe2_pmc_hbm.csv): (2 x FETCH_SIZE [gfx950 correction, MI355X_MICROARCH.md HBM] + WRITE_SIZE) x 1024
+# = (2 * 751100 + 133300) KiB.  Reported only when the run is that kernel at that shape.
+ATTN_TRAFFIC = {"kernel": "ld_attn_pipe2_w4_kernel", "bytes": (2 * 751100 + 133300) * 1024}
 
 
 def cpu_baseline(cfg, budget_s: float = 25.0):
@@ -98,8 +102,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N-GPU runs with "
+                         "`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...`")
     import torch.distributed as dist
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
@@ -162,6 +166,11 @@ def main():
         flops = 4.0 * 2 * d.heads * d.seq_len * d.seq_len * d.head_dim      # algorithmic FLOPs of one launch
         achieved = flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
         peak = 2500.0
+        from landiff_amd import _lib
+        kname = (_lib.load().ld_attn_last_kernel() or b"").decode()      # what the launcher actually ran (shape + LD_ATTN_* knobs)
+        # the PMC traffic figure was collected on the default kernel at the headline shape only (profiles/, see ATTN_TRAFFIC)
+        headline = (not args.tiny and not stream and not args.fp8_gemm and kname == ATTN_TRAFFIC["kernel"]
+                    and not any(os.environ.get(k) for k in ("LD_ATTN_NW", "LD_ATTN_SAFE", "LD_ATTN_VARIANT")))
         res = {
             "metric": METRIC, "value": world * n_frames * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -178,12 +187,10 @@ def main():
                        "sampler_steps": cfg.sampler.num_steps, "llm_steps": (1244 if not stream else None) if not args.tiny else None,
                        "parallelism": f"dp{world} over prompts, RCCL all_gather of uint8 frames only"},
             "stage_seconds_rank0": {k: round(v / args.steps, 3) for k, v in pipe.timings.items()},
-            "roofline": {"kernel": "ld_attn_pipe2_w4_kernel (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (d.heads, d.seq_len),
+            "roofline": {"kernel": "%s (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (kname, d.heads, d.seq_len),
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
-                         # HBM bytes per launch from rocprofv3 PMC passes at this shape (profiles/r01c_attn_pipe2_pmc_hbm.csv):
-                         # (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) x 1024 = (2*751100 + 133300) KiB
-                         "traffic": (2 * 751100 + 133300) * 1024 if not args.tiny else None, "launches": len(ev),
+                         "traffic": ATTN_TRAFFIC["bytes"] if headline else None, "launches": len(ev),
                          "avg_launch_ms": round(attn_ms, 4)},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -123,6 +123,10 @@ int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
                      const int32_t* fid_q, const int32_t* fid_k,
                      const int32_t* kt_min, const int32_t* kt_max, void* stream);
 
+/* Name of the kernel the calling thread's last ld_attn_fwd_bf16 launched ("" before the first call): the launcher picks
+ * by shape and tuning environment, and measurement code must label what actually ran. */
+const char* ld_attn_last_kernel(void);
+
 /* ---- tokenizer encoder side (ld_tokenize.hip) ---- */
 
 /* VideoVQ.norm_features + the "b t c h w -> b (t h w) c" rearrange in front of TiTokEncoder.patch_embed
@@ -130,6 +134,11 @@ int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
  * features [T][C][P] (fp32 if in_f32 else bf16, P = h*w) -> out [T*P][C] bf16 = bf16((x - mean[c]) / (std[c] + 1e-8)). */
 int ld_feature_norm_cl(const void* features, int32_t in_f32, const float* mean, const float* stdv, void* out,
                        int64_t T, int64_t C, int64_t P, void* stream);
+
+/* VideoVQ.denorm_features (video_titok_vq.py:228-233; active only when the config names a mean_std_path) on the
+ * channels-last decoder output, then the cast back to the module dtype (condition.py:103-104):
+ * x bf16 [rows][C] -> out bf16 = bf16(float(x) * (std[c] + 1e-8) + mean[c]).  out may alias x. */
+int ld_feature_denorm(const void* x, const float* mean, const float* stdv, void* out, int64_t rows, int64_t C, void* stream);
 
 /* Nearest code of vector-quantize-pytorch's EuclideanCodebook.forward in eval (argmax of -cdist, fp32), called by
  * VideoVQ.encode_to_index (video_titok_vq.py:196-200): x bf16 [rows][ldx] (first dim columns), codebook fp32 [V][dim]
@@ -225,8 +234,12 @@ int ld_qkv_split(const void* qkv, void* Q, void* K, void* Vt, int64_t B, int64_t
                  int32_t mode, const void* q_w, const void* q_b, const void* k_w, const void* k_b, float eps,
                  const float* cos_t, const float* sin_t, void* stream);
 
-/* GroupNorm statistics of channels-last x [F][P][C]: stats[f][g] += (sum, sum of squares) in double (zero it first). */
-int ld_groupnorm_stats(const void* x, double* stats, int64_t F, int64_t P, int64_t C, int64_t G, void* stream);
+/* GroupNorm statistics of channels-last x [F][P][C] (torch.nn.GroupNorm inside Normalize, vq_gan_blocks.py:35-38, and
+ * SpatialNorm3D, cp_enc_dec.py:546-569): stats[f][g] = (sum, sum of squares) in double.  No floating-point atomics:
+ * partials is a caller-owned workspace of F * ld_groupnorm_stats_blocks(P) * G * 2 doubles, reduced in a fixed order, so
+ * the result is bit-identical from run to run.  stats need not be zeroed. */
+int64_t ld_groupnorm_stats_blocks(int64_t P);
+int ld_groupnorm_stats(const void* x, double* stats, double* partials, int64_t F, int64_t P, int64_t C, int64_t G, void* stream);
 
 /* y = swish?( GN(x) [* zy + zb] ) written into the interior of a zero-bordered channels-last buffer
  * [F][T+tpad][H+2*hpad][W+2*wpad][C]; zy/zb [Tz][Hz][Wz][C] are conv_y(zq)/conv_b(zq) at latent resolution, gathered

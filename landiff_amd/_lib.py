@@ -55,6 +55,7 @@ SIGNATURES: dict[str, list] = {
     "ld_gemm_bf16": [P, I64, P, P, I64, I64, I64, I64, POINTER(Epilogue), P],
     "ld_conv_cl_bf16": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, POINTER(Epilogue), P],
     "ld_attn_fwd_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_float, P, P, P, P, P],
+    "ld_attn_last_kernel": [],
     "ld_gemv": [P, I64, I32, P, P, I32, P, P, I64, P, I64, I32, I64, I64, I64, I32, I32, P, c_float, P],
     "ld_rmsnorm_bf16": [P, P, P, I64, I64, c_float, P],
     "ld_layernorm_bf16_to_f32": [P, I64, P, P, P, I64, I64, c_float, P],
@@ -67,6 +68,7 @@ SIGNATURES: dict[str, list] = {
     "ld_layernorm_mxfp8": [P, I64, P, P, P, I64, P, I64, I64, I64, c_float, P, I64, I64, I64, I64, I64, I64, I64, P],
     "ld_gemm_mxfp8": [P, I64, P, P, P, P, I64, P, I64, I64, I64, I64, P, P],
     "ld_feature_norm_cl": [P, I32, P, P, P, I64, I64, I64, P],
+    "ld_feature_denorm": [P, P, P, P, I64, I64, P],
     "ld_vq_nearest": [P, I64, P, P, I64, I64, I64, P],
     "ld_llm_decode_forward": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
                               c_float, c_float, P],
@@ -74,7 +76,8 @@ SIGNATURES: dict[str, list] = {
     "ld_llm_decode_advance": [P, P, P, P, P, P, P],
     "ld_layernorm": [P, I64, I32, P, P, P, I64, I32, I64, I64, c_float, P, I64, I64, I64, I64, I64, I64, I64, P],
     "ld_qkv_split": [P, P, P, P, I64, I64, I64, I64, I32, P, P, P, P, c_float, P, P, P],
-    "ld_groupnorm_stats": [P, P, I64, I64, I64, I64, P],
+    "ld_groupnorm_stats_blocks": [I64],
+    "ld_groupnorm_stats": [P, P, P, I64, I64, I64, I64, P],
     "ld_groupnorm_apply": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I32, c_float, P],
     "ld_patchify": [P, P, P, I64, I64, I64, I64, I64, I64, P],
     "ld_unpatchify_cfg": [P, P, P, I64, I64, I64, I64, I64, c_float, c_float, c_float, P],
@@ -102,7 +105,8 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_char_p if name == "ld_last_error" else c_int
+        fn.restype = (c_char_p if name in ("ld_last_error", "ld_attn_last_kernel") else
+                      ctypes.c_int64 if name == "ld_groupnorm_stats_blocks" else c_int)
     _lib = lib
     return lib
 

@@ -78,6 +78,10 @@ class TokenizerConfig:
     out_channels: int = 768
     rope_theta: float = 10000.0
     ln_eps: float = 1e-5
+    # VideoVQ.norm_features / denorm_features act only when `mean_std_path is not None` (video_titok_vq.py:221-233); the
+    # shipped tokenizer_cfg.py:107 sets only `mean_std_dim=768`, so the `mean`/`std` buffers exist in the checkpoint but both
+    # functions are the identity.  True mirrors a config that names a mean_std_path.
+    norm_features: bool = False
 
     @property
     def head_dim(self): return self.width // self.heads

@@ -20,5 +20,19 @@ int ld_check_launch(const char* what) {
   return LD_OK;
 }
 
+int ld_ensure_dyn_smem(const void* kernel, size_t bytes, LdSmemCache* cache) {
+  if (bytes <= 48 * 1024) return LD_OK;                       // the default limit needs no opt-in
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return ld_set_error(LD_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+  const bool cached = dev >= 0 && dev < 16;
+  if (cached && cache->bytes[dev] >= bytes) return LD_OK;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess)
+    return ld_set_error(LD_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) on device %d: %s", bytes, dev, hipGetErrorString(e));
+  if (cached) cache->bytes[dev] = bytes;
+  return LD_OK;
+}
+
 LD_API int ld_version(void) { return LD_ABI_VERSION; }
 LD_API const char* ld_last_error(void) { return g_err; }

@@ -341,6 +341,11 @@ __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
 
 int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st);   // ld_attn_pipe.hip
 
+// name of the kernel the calling thread's last ld_attn_fwd_bf16 launched (bench.py labels its roofline object with it)
+static thread_local const char* g_attn_last_kernel = "";
+void ld_attn_set_last_kernel(const char* name) { g_attn_last_kernel = name; }
+LD_API const char* ld_attn_last_kernel(void) { return g_attn_last_kernel; }
+
 LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
                             int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
                             int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
@@ -372,8 +377,15 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   const int64_t nkt = (Nk + KT - 1) / KT;
   if ((var == 0 || var == 8) && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {
     return ld_attn_pipe2_launch(p, st);
-  } else if (var == 1) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);
-  else if (var == 4) hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 4>), grid, block, s1, st, p);
-  else hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 3>), grid, block, s1, st, p);
+  } else if (var == 1) {
+    g_attn_last_kernel = "ld_attn_kernel<1,true,false,true,2>";
+    hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);
+  } else if (var == 4) {
+    g_attn_last_kernel = "ld_attn_kernel<1,true,false,false,4>";
+    hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 4>), grid, block, s1, st, p);
+  } else {
+    g_attn_last_kernel = "ld_attn_kernel<1,true,false,false,3>";
+    hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 3>), grid, block, s1, st, p);
+  }
   return ld_check_launch("ld_attn_fwd_bf16");
 }

@@ -339,6 +339,8 @@ __global__ __launch_bounds__(512, 2) void ld_attn_pipe2_w8_kernel(AttnParams p, 
 
 }  // namespace
 
+void ld_attn_set_last_kernel(const char* name);   // ld_attn.hip
+
 // LD_ATTN_SAFE=1 forces the running-max pass (testing / A-B timing); LD_ATTN_NW=4|8 picks the workgroup size.
 int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st) {
   constexpr int SMEM = 8 * KTILE_BYTES + 64;
@@ -346,11 +348,14 @@ int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st) {
   if (safe < 0) {
     const char* e = getenv("LD_ATTN_SAFE"); safe = e ? atoi(e) : 0;
     const char* w = getenv("LD_ATTN_NW"); if (w && atoi(w) == 8) nw = 8;
-    (void)hipFuncSetAttribute((const void*)ld_attn_pipe2_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    (void)hipFuncSetAttribute((const void*)ld_attn_pipe2_w8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
+  static thread_local LdSmemCache c4{}, c8{};
+  if (int rc = nw == 4 ? ld_ensure_dyn_smem((const void*)ld_attn_pipe2_w4_kernel, SMEM, &c4)
+                       : ld_ensure_dyn_smem((const void*)ld_attn_pipe2_w8_kernel, SMEM, &c8)) return rc;
   const int qbw = nw * 32;
   dim3 grid((unsigned)((long)p.B * p.H * ((p.Npad + qbw - 1) / qbw)));
+  ld_attn_set_last_kernel(nw == 4 ? (safe ? "ld_attn_pipe2_w4_kernel[safe pass forced]" : "ld_attn_pipe2_w4_kernel")
+                                  : (safe ? "ld_attn_pipe2_w8_kernel[safe pass forced]" : "ld_attn_pipe2_w8_kernel"));
   if (nw == 4) hipLaunchKernelGGL(ld_attn_pipe2_w4_kernel, grid, dim3(256), SMEM, st, p, safe);
   else hipLaunchKernelGGL(ld_attn_pipe2_w8_kernel, grid, dim3(512), SMEM, st, p, safe);
   return ld_check_launch("ld_attn_fwd_bf16(pipe2)");

@@ -16,6 +16,12 @@ enum {
 int ld_set_error(int code, const char* fmt, ...);
 int ld_check_launch(const char* what);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: the memo of "already raised to N bytes" is kept
+// per device and per host thread (declare the cache `static thread_local` at the call site, one per kernel), and the
+// return code of the runtime call is checked.
+struct LdSmemCache { size_t bytes[16]; };     // indexed by device ordinal; devices >= 16 are never cached
+int ld_ensure_dyn_smem(const void* kernel, size_t bytes, LdSmemCache* cache);
+
 #define LD_REQUIRE(cond, ...)                                  \
   do {                                                         \
     if (!(cond)) return ld_set_error(LD_ERR_INVALID, __VA_ARGS__); \

@@ -1178,11 +1178,8 @@ __global__ __launch_bounds__(256, 1) void ld_gemm_w4r_kernel(GemmParams p) {
 
 template <auto Kernel>
 int launch_kernel(const char* what, dim3 grid, dim3 block, int smem, hipStream_t stream, const GemmParams& p) {
-  static bool attr_set = false;      // per kernel instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  static thread_local LdSmemCache cache{};      // per kernel instantiation (and per host thread, per device inside)
+  if (int rc = ld_ensure_dyn_smem((const void*)Kernel, (size_t)smem, &cache)) return rc;
   hipLaunchKernelGGL(Kernel, grid, block, smem, stream, p);
   return ld_check_launch(what);
 }

@@ -865,11 +865,8 @@ __global__ void ld_decode_advance_kernel(const long* sampled, const int* forced,
 template <int B, bool WF32, int R>
 int launch_gemv_cfg(const GemvParams& p, hipStream_t st) {
   const size_t smem = (size_t)B * p.K * (WF32 ? 4 : 2) + 64;
-  static size_t attr = 48 * 1024;
-  if (smem > attr) {
-    (void)hipFuncSetAttribute((const void*)ld_gemv_kernel<B, WF32, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr = smem;
-  }
+  static thread_local LdSmemCache cache{};      // per instantiation
+  if (int rc = ld_ensure_dyn_smem((const void*)ld_gemv_kernel<B, WF32, R>, smem, &cache)) return rc;
   // persistent grid: ~2 workgroups per CU (or fewer when there are not enough rows); every wave loops over row groups
   long blocks = (p.N + 4 * R - 1) / (4 * R);
   if (blocks > 512) blocks = 512;
@@ -1004,11 +1001,8 @@ LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cach
   LD_REQUIRE(q && !qkv_fused, "ld_llm_kv_attn: the fused RoPE/append form exists only for the decode split path");
   const size_t smem = (size_t)(Lmax + 8 + 256) * sizeof(float);
   LD_REQUIRE(smem <= 160 * 1024, "ld_llm_kv_attn: Lmax=%ld too long for the LDS score buffer", (long)Lmax);
-  static size_t attr = 0;
-  if (smem > attr) {
-    (void)hipFuncSetAttribute((const void*)ld_kv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr = smem;
-  }
+  static thread_local LdSmemCache cache{};
+  if (int rc = ld_ensure_dyn_smem((const void*)ld_kv_attn_kernel, smem, &cache)) return rc;
   hipLaunchKernelGGL(ld_kv_attn_kernel, dim3((unsigned)(B * H), (unsigned)m), dim3(256), smem, st,
                      (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, (const int*)pos,
                      (bf16_t*)out, (int)B, (int)m, (int)H, (int)Lmax);

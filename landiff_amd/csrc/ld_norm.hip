@@ -318,12 +318,15 @@ __global__ __launch_bounds__(256) void ld_qkv_split_kernel(SplitParams p) {
 
 // ---------------------------------------------------------------------------------------------
 // GroupNorm statistics over a channels-last tensor x [F][P][C]: per (frame-group f, group g) sum and sum of
-// squares, accumulated in double with one atomic pair per workgroup.  stats [F][G][2] must be zeroed.
+// squares in double.  No floating-point atomics anywhere: every workgroup writes its partial pair to
+// partials [F][nblk][G][2] and ld_gn_stats_reduce_kernel sums them in a fixed order, so the statistics -- and with them the
+// whole VAE / upsampler decode -- are bit-identical from run to run.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ld_gn_stats_kernel(const bf16_t* x, double* stats, long P, int C, int G, int rows_per_block) {
-  // Per-thread partials are combined in a FIXED order (no floating-point atomics inside the block): the fp32 LDS atomics
-  // this replaced made the statistics differ by ~6e-7 from run to run, which a 30-layer decoder amplifies into visible
-  // last-bit noise.  Across blocks the fp64 atomics remain (order noise ~1e-16 relative).
+constexpr int GN_ROWS_PER_BLOCK = 512;
+
+__global__ __launch_bounds__(256) void ld_gn_stats_kernel(const bf16_t* x, double* partials, long P, int C, int G, int rows_per_block) {
+  // Per-thread partials are combined in a FIXED order: the fp32 LDS atomics this replaced made the statistics differ by
+  // ~6e-7 from run to run, which a 30-layer decoder amplifies into visible last-bit noise.
   __shared__ float part[2][256][4];   // [sum | sumsq][thread][sub-group of the thread's 8 channels]
   const int f = blockIdx.y;
   const long p0 = (long)blockIdx.x * rows_per_block;
@@ -366,9 +369,22 @@ __global__ __launch_bounds__(256) void ld_gn_stats_kernel(const bf16_t* x, doubl
         const int t = rl * chunks_per_row + c;
         s += (double)part[0][t][q]; ss += (double)part[1][t][q];
       }
-    atomicAdd(&stats[((long)f * G + tid) * 2 + 0], s);
-    atomicAdd(&stats[((long)f * G + tid) * 2 + 1], ss);
+    double* o = partials + (((long)f * gridDim.x + blockIdx.x) * G + tid) * 2;
+    o[0] = s; o[1] = ss;
   }
+}
+
+// One wave per (f, g): lane l sums blocks l, l + 64, ... in index order, then a fixed butterfly.
+__global__ __launch_bounds__(64) void ld_gn_stats_reduce_kernel(const double* partials, double* stats, int nblk, int G) {
+  const int fg = blockIdx.x, f = fg / G, g = fg - f * G, lane = threadIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (int b = lane; b < nblk; b += 64) {
+    const double* q = partials + (((long)f * nblk + b) * G + g) * 2;
+    s += q[0]; ss += q[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+  if (lane == 0) { stats[(long)fg * 2] = s; stats[(long)fg * 2 + 1] = ss; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -485,14 +501,18 @@ LD_API int ld_qkv_split(const void* qkv, void* Q, void* K, void* Vt, int64_t B, 
   return ld_check_launch("ld_qkv_split");
 }
 
-LD_API int ld_groupnorm_stats(const void* x, double* stats, int64_t F, int64_t P, int64_t C, int64_t G, void* stream) {
-  LD_REQUIRE(x && stats, "ld_groupnorm_stats: null pointer");
+LD_API int64_t ld_groupnorm_stats_blocks(int64_t P) { return (P + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK; }
+
+LD_API int ld_groupnorm_stats(const void* x, double* stats, double* partials, int64_t F, int64_t P, int64_t C, int64_t G, void* stream) {
+  LD_REQUIRE(x && stats && partials, "ld_groupnorm_stats: null pointer");
   LD_REQUIRE(C % 8 == 0 && C / 8 <= 256 && G <= 64 && C % G == 0, "ld_groupnorm_stats: unsupported C=%ld G=%ld", (long)C, (long)G);
   const int cpg = (int)(C / G);
   LD_REQUIRE(cpg % 8 == 0 || 8 % cpg == 0, "ld_groupnorm_stats: channels per group %d unsupported", cpg);
-  const int rows_per_block = 512;
-  dim3 grid((unsigned)((P + rows_per_block - 1) / rows_per_block), (unsigned)F), block(256);
-  hipLaunchKernelGGL(ld_gn_stats_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, stats, (long)P, (int)C, (int)G, rows_per_block);
+  const int rows_per_block = GN_ROWS_PER_BLOCK;
+  const int nblk = (int)ld_groupnorm_stats_blocks(P);
+  dim3 grid((unsigned)nblk, (unsigned)F), block(256);
+  hipLaunchKernelGGL(ld_gn_stats_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, partials, (long)P, (int)C, (int)G, rows_per_block);
+  hipLaunchKernelGGL(ld_gn_stats_reduce_kernel, dim3((unsigned)(F * G)), dim3(64), 0, (hipStream_t)stream, (const double*)partials, stats, nblk, (int)G);
   return ld_check_launch("ld_groupnorm_stats");
 }
 

@@ -35,6 +35,16 @@ __global__ __launch_bounds__(256) void ld_feature_norm_cl_kernel(const void* in,
   }
 }
 
+// x [rows][C] bf16 (channels-last decoder features) -> out bf16 = bf16(float(x) * (std[c] + 1e-8) + mean[c]): the fp32
+// promotion of VideoVQ.denorm_features followed by SemanticCond's cast back to the module dtype.
+__global__ __launch_bounds__(256) void ld_feature_denorm_kernel(const bf16_t* x, const float* mean, const float* stdv,
+                                                                bf16_t* out, long n, int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  out[i] = f2bf(bf2f(x[i]) * (stdv[c] + 1e-8f) + mean[c]);
+}
+
 // One wave per row: idx[row] = first code minimising |x|^2 + |e|^2 - 2 x.e (clamped at 0), all fp32.
 __global__ __launch_bounds__(256) void ld_vq_nearest_kernel(const bf16_t* x, long ldx, const float* codebook, long* idx,
                                                             int rows, int V, int dim) {
@@ -77,6 +87,15 @@ LD_API int ld_feature_norm_cl(const void* features, int32_t in_f32, const float*
   else hipLaunchKernelGGL(ld_feature_norm_cl_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, features, mean, stdv,
                           (bf16_t*)out, (int)C, (int)P);
   return ld_check_launch("ld_feature_norm_cl");
+}
+
+LD_API int ld_feature_denorm(const void* x, const float* mean, const float* stdv, void* out, int64_t rows, int64_t C,
+                             void* stream) {
+  LD_REQUIRE(x && mean && stdv && out && rows > 0 && C > 0, "ld_feature_denorm: bad args");
+  const long n = (long)rows * C;
+  hipLaunchKernelGGL(ld_feature_denorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, mean, stdv, (bf16_t*)out, n, (int)C);
+  return ld_check_launch("ld_feature_denorm");
 }
 
 LD_API int ld_vq_nearest(const void* x, int64_t ldx, const float* codebook, int64_t* idx, int64_t rows, int64_t V,

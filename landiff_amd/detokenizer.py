@@ -75,6 +75,10 @@ class Detokenizer:
         self.ln_post = (g("decoder.ln_post.weight"), g("decoder.ln_post.bias"))
         self.ffn0 = (g("decoder.ffn.0.weight"), g("decoder.ffn.0.bias"))
         self.ffn2 = (g("decoder.ffn.2.weight"), g("decoder.ffn.2.bias"))
+        # denorm_features: identity unless the config names a mean_std_path (video_titok_vq.py:228-233)
+        self.denorm = None
+        if tc.norm_features:
+            self.denorm = (_dev(tok_sd["mean"].reshape(-1), device, torch.float32), _dev(tok_sd["std"].reshape(-1), device, torch.float32))
         self.blocks = []
         for i in range(tc.layers):
             p = f"decoder.transformer.{i}."
@@ -142,6 +146,8 @@ class Detokenizer:
         ops.layernorm(x[:nv], *self.ln_post, ln[:nv], tc.ln_eps)
         f1 = ops.gemm(ln[:nv], self.ffn0[0], bias=self.ffn0[1], act="tanh")
         feats = ops.gemm(f1, self.ffn2[0], bias=self.ffn2[1])
+        if self.denorm is not None:
+            ops.feature_denorm(feats, *self.denorm)
         return feats.view(tc.temporal, tc.grid_h, tc.grid_w, tc.out_channels)
 
     # ---- conv upsampler -------------------------------------------------------------------

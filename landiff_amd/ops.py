@@ -328,6 +328,17 @@ def feature_norm_cl(features, mean, std, out, T, C, P):
                                          T, C, P, _stream()), "ld_feature_norm_cl")
 
 
+def feature_denorm(x, mean, std, out=None):
+    """x bf16 [rows, C] -> bf16(float(x) * (std[c] + 1e-8) + mean[c]) (VideoVQ.denorm_features when a mean_std_path is configured)."""
+    _bf16(x, "x")
+    assert x.is_contiguous() and mean.dtype == torch.float32 and std.dtype == torch.float32
+    out = x if out is None else out
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape == x.shape
+    check(_lib.load().ld_feature_denorm(_ptr(x), _ptr(mean), _ptr(std), _ptr(out), x.shape[0], x.shape[1], _stream()),
+          "ld_feature_denorm")
+    return out
+
+
 def vq_nearest(x, codebook, idx, dim):
     """x bf16 [rows, >=dim], codebook fp32 [V, dim] -> idx int64 [rows] (first code at minimum Euclidean distance)."""
     _bf16(x, "x")
@@ -348,9 +359,12 @@ def qkv_split(qkv, q, k, vt, B, N, H, Npad, *, ln=None, rope=None, eps=1e-6):
 
 
 def groupnorm_stats(x, stats, F, P, C, G):
-    assert stats.dtype == torch.float64
-    stats.zero_()
-    check(_lib.load().ld_groupnorm_stats(_ptr(x), _ptr(stats), F, P, C, G, _stream()), "ld_groupnorm_stats")
+    """stats [F, G, 2] float64 <- (sum, sum of squares) per frame-group and channel group; deterministic (fixed-order
+    reduction of per-workgroup partials through a workspace from torch's caching allocator)."""
+    assert stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() == F * G * 2
+    lib = _lib.load()
+    ws = torch.empty(F * int(lib.ld_groupnorm_stats_blocks(P)) * G * 2, device=stats.device, dtype=torch.float64)
+    check(lib.ld_groupnorm_stats(_ptr(x), _ptr(stats), _ptr(ws), F, P, C, G, _stream()), "ld_groupnorm_stats")
 
 
 def groupnorm_apply(x, out_padded, stats, gamma, beta, F, T, H, W, C, G, *, zy=None, zb=None, zshape=(1, 1, 1),

@@ -56,7 +56,14 @@ class TokenizerEncoder:
         g = lambda k: _dev(enc_sd[k], device)
         f32 = lambda k: _dev(enc_sd[k], device, torch.float32)
         w = tc.width
-        self.mean, self.std = f32("mean"), f32("std")
+        # norm_features is the identity unless the config names a mean_std_path (video_titok_vq.py:221-226; the shipped
+        # tokenizer_cfg.py only sets mean_std_dim, so the checkpoint's buffers are NOT applied): zeros / ones make the
+        # same kernel an exact pass-through ((x - 0) / (1 + 1e-8f) == x in fp32) that still does the channels-last transpose
+        if tc.norm_features:
+            self.mean, self.std = f32("mean"), f32("std")
+        else:
+            self.mean = torch.zeros(tc.out_channels, device=device, dtype=torch.float32)
+            self.std = torch.ones(tc.out_channels, device=device, dtype=torch.float32)
         self.patch_w, self.patch_b = g("encoder.patch_embed.weight").reshape(w, -1).contiguous(), g("encoder.patch_embed.bias")
         self.latent = torch.cat([g("encoder.IFrame_latent_tokens"),
                                  g("encoder.PFrame_latent_tokens").repeat(tc.temporal - 1, 1)], 0).contiguous()
@@ -103,7 +110,7 @@ class TokenizerEncoder:
         T, C, gh, gw = features.shape
         assert (T, C, gh, gw) == (tc.temporal, tc.out_channels, tc.grid_h, tc.grid_w), features.shape
         xin = torch.empty(nv, C, device=dev, dtype=BF)
-        ops.feature_norm_cl(features.contiguous(), self.mean, self.std, xin, T, C, gh * gw)       # (x-mean)/(std+1e-8) -> bf16
+        ops.feature_norm_cl(features.contiguous(), self.mean, self.std, xin, T, C, gh * gw)       # norm_features (identity by default) -> bf16, channels-last
         x0 = torch.empty(N, w, device=dev, dtype=BF)
         ops.gemm(xin, self.patch_w, out=x0[:nv], bias=self.patch_b)                               # 1x1 patch embedding
         x0[nv:] = self.latent

@@ -296,7 +296,9 @@ def resolve_ckpt_root(repo_root: str | None = None) -> str:
 def _sat_module(path_dir: str) -> dict:
     with open(os.path.join(path_dir, "latest")) as f:
         it = f.read().strip()
-    sd = torch.load(os.path.join(path_dir, it, "mp_rank_00_model_states.pt"), map_location="cpu")
+    # a full pickle (argparse namespaces next to the tensors): torch >= 2.6 defaults to weights_only=True and would refuse it;
+    # the reference loads these trusted local files with the old default (dit_video_concat.py:1176, sat load_checkpoint)
+    sd = torch.load(os.path.join(path_dir, it, "mp_rank_00_model_states.pt"), map_location="cpu", weights_only=False)
     return sd["module"]
 
 
@@ -339,6 +341,6 @@ def load_diffusion_states(diffusion_dir: str, root: str) -> dict:
     sem = _sub(ctrl_all, "semantic_conditioner.")
     tok = _sub(sem, "semantic_model.model.")
     ups = {k: v for k, v in sem.items() if k.startswith("upsample_model.") or k.startswith("conv_out.")}
-    vae_sd = torch.load(os.path.join(root, CKPT_FILES["vae"]), map_location="cpu")["state_dict"]
+    vae_sd = torch.load(os.path.join(root, CKPT_FILES["vae"]), map_location="cpu", weights_only=False)["state_dict"]   # lightning pickle
     vae = {k: v for k, v in vae_sd.items() if k.startswith("decoder.")}
     return {"dit_main": main, "dit_control": ctrl, "tok": tok, "ups": ups, "vae": vae}

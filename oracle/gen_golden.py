@@ -329,6 +329,23 @@ def gen_titok():
     save("titok_fp32", z=z, out=out, seed=np.array(6))
 
 
+def gen_feature_norm():
+    """VideoVQ.norm_features / denorm_features (video_titok_vq.py:221-233) called as the reference's own unbound methods,
+    once with mean_std_path=None (the shipped tokenizer_cfg.py: buffers present, functions the identity) and once with
+    a path set: pins the gate, not just the formula."""
+    from landiff.tokenizer.models.video_titok_vq import VideoVQ as TowDVQ
+    g = torch.Generator().manual_seed(21)
+    C = 8
+    x = torch.randn(1, 3, C, 4, 6, generator=g)
+    mean, std = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    off = types.SimpleNamespace(mean_std_path=None, mean=mean, std=std)
+    on = types.SimpleNamespace(mean_std_path="stats.pt", mean=mean, std=std)
+    save("feature_norm", x=x, mean=mean, std=std,
+         norm_off=TowDVQ.norm_features(off, x), norm_on=TowDVQ.norm_features(on, x),
+         denorm_off=TowDVQ.denorm_features(off, x), denorm_on=TowDVQ.denorm_features(on, x),
+         denorm_on_bf16=TowDVQ.denorm_features(on, x.to(torch.bfloat16)).to(torch.bfloat16))
+
+
 def gen_titok_encoder():
     """Encoder half: TiTokEncoder.forward on a tiny config + VideoEncoderMask (tiny dense through the
     reference's scalar _mask_fn; full size through its vectorised vmap_fn, hashed)."""
@@ -365,6 +382,8 @@ def gen_titok_encoder():
     with torch.no_grad():
         out = enc(x, forward_T=cfg.temporal)                                       # [1, token_size, 1, L]
     save("titok_enc_fp32", x=x, out=out, seed=np.array(8))
+
+    gen_feature_norm()
 
     def make_mask_obj(T, tpf, nI, nP):
         m = object.__new__(fam.VideoEncoderMask)

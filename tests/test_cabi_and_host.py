@@ -150,3 +150,42 @@ def test_tokenizer_encoder_checkpoint_loader(tmp_path):
     save_file({k: v.contiguous() for k, v in sd.items()}, f)
     out = load_tokenizer_encoder_state(f)
     assert float(out["mean"].abs().max()) == 0.0 and float((out["std"] - 1).abs().max()) == 0.0
+
+
+def test_sat_checkpoint_layout_round_trip(tmp_path):
+    """load_diffusion_states on a miniature of the reference's checkpoint tree (ckpts/README.md:27-45): sat `.pt` files with
+    ['module'] + a `latest` pointer, the lightning VAE `.pt` with ['state_dict'], each a FULL pickle carrying non-tensor
+    metadata (argparse namespaces) -- torch >= 2.6 refuses those under its weights_only default."""
+    import argparse
+    import torch
+    from landiff_amd.weights import load_diffusion_states
+    root = tmp_path / "LanDiff"
+    t = lambda *s: torch.randn(*s)
+    base = {"model.diffusion_model.transformer.layers.0.mlp.dense_h_to_4h.weight": t(8, 2),
+            "model.diffusion_model.mixins.pos_embed.pos_embedding": t(1, 4, 2)}
+    ctl = "model.control_model.diffusion_model."
+    mod = {"model.main_model.diffusion_model.mixins.final_layer.linear.weight": t(4, 2),
+           ctl + "transformer.layers.0.mlp.dense_h_to_4h.weight": t(8, 2),                    # overrides the base weight
+           ctl + "mixins.adaln_layer.zero_linears.0.weight": t(2, 2),
+           ctl + "semantic_conditioner.semantic_model.model.decoder.mask_token": t(1, 1, 2),
+           ctl + "semantic_conditioner.semantic_model.model.mean": t(2),
+           ctl + "semantic_conditioner.upsample_model.conv_in.weight": t(2, 2, 3, 3),
+           ctl + "semantic_conditioner.conv_out.weight": t(2, 2, 3, 3)}
+    vae = {"decoder.conv_in.conv.weight": t(2, 2, 3, 3, 3), "loss.discriminator.w": t(2), "encoder.conv_in.conv.weight": t(2)}
+    for d, sd in ((root / "diffusion", mod), (root / "CogVideoX-2b-sat" / "transformer", base)):
+        (d / "1").mkdir(parents=True)
+        (d / "latest").write_text("1\n")
+        torch.save({"module": sd, "args": argparse.Namespace(mode="inference", bf16=True)}, d / "1" / "mp_rank_00_model_states.pt")
+    (root / "CogVideoX-2b-sat" / "vae").mkdir(parents=True)
+    torch.save({"state_dict": vae, "hyper_parameters": argparse.Namespace(lr=1e-4)}, root / "CogVideoX-2b-sat" / "vae" / "3d-vae.pt")
+    out = load_diffusion_states(str(root / "diffusion"), str(root))
+    assert set(out) == {"dit_main", "dit_control", "tok", "ups", "vae"}
+    k = "transformer.layers.0.mlp.dense_h_to_4h.weight"
+    assert torch.equal(out["dit_main"][k], base["model.diffusion_model." + k])                # base weights, final layer added
+    assert "mixins.final_layer.linear.weight" in out["dit_main"]
+    assert torch.equal(out["dit_control"][k], mod[ctl + k])                                   # control ckpt overrides the base
+    assert "mixins.adaln_layer.zero_linears.0.weight" in out["dit_control"]
+    assert not any(x.startswith("semantic_conditioner.") for x in out["dit_control"])
+    assert set(out["tok"]) == {"decoder.mask_token", "mean"}
+    assert set(out["ups"]) == {"upsample_model.conv_in.weight", "conv_out.weight"}
+    assert set(out["vae"]) == {"decoder.conv_in.conv.weight"}

@@ -55,6 +55,41 @@ def test_encoder_matches_oracle(cuda, name):
     assert torch.equal(idx[clear], top2.indices[:, 0][clear])
 
 
+def test_norm_features_gate(cuda):
+    """The checkpoint's mean/std buffers are applied only when the config names a mean_std_path (video_titok_vq.py:221-233;
+    the shipped tokenizer_cfg.py does not): with the flag off, non-trivial statistics in the state dict must not change a
+    single token id; with it on, encoder and decoder follow the reference's formulas (golden: its own two methods)."""
+    import dataclasses, os
+    from landiff_amd import ops
+    from landiff_amd.tokenizer_encoder import TokenizerEncoder
+    from landiff_amd.weights import init_state, tokenizer_encoder_spec
+    from oracle.tokenizer import TokenizerEncoderOracle
+    cfg = _cfgs()["mid"]
+    sd = init_state(tokenizer_encoder_spec(cfg), 17)
+    g = torch.Generator().manual_seed(3)
+    sd_stats = dict(sd, mean=torch.randn(cfg.out_channels, generator=g), std=torch.rand(cfg.out_channels, generator=g) + 0.5)
+    sd_plain = dict(sd, mean=torch.zeros(cfg.out_channels), std=torch.ones(cfg.out_channels))
+    x = _features(cfg, 5).to(cuda)
+    z_off = TokenizerEncoder(sd_stats, cfg, cuda).encode(x)
+    z_plain = TokenizerEncoder(sd_plain, cfg, cuda).encode(x)
+    assert torch.equal(z_off, z_plain)                                           # buffers ignored: bit-identical latents
+    assert torch.equal(TokenizerEncoder(sd_stats, cfg, cuda).encode_to_index(x), TokenizerEncoder(sd_plain, cfg, cuda).encode_to_index(x))
+    on = dataclasses.replace(cfg, norm_features=True)
+    z_on = TokenizerEncoder(sd_stats, on, cuda).encode(x).float().cpu()
+    assert (z_on - z_off.float().cpu()).abs().max().item() > 1e-2                # the flag does change the input
+    orc = TokenizerEncoderOracle(sd_stats, on, torch.bfloat16)
+    ref = orc.encode(orc.norm_features(x.cpu()[None]))[0].float()
+    assert (z_on - ref).abs().max().item() / (ref.abs().max().item() + 1e-6) < 3e-2
+    # decoder side: ld_feature_denorm against the reference's denorm_features (bf16 features, fp32 buffers, cast back to bf16)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "feature_norm.npz"))
+    xg = torch.from_numpy(gold["x"]).to(torch.bfloat16).permute(0, 1, 3, 4, 2).contiguous()          # channels-last
+    C = xg.shape[-1]
+    out = ops.feature_denorm(xg.reshape(-1, C).to(cuda), torch.from_numpy(gold["mean"]).to(cuda), torch.from_numpy(gold["std"]).to(cuda),
+                             out=torch.empty(xg.numel() // C, C, device=cuda, dtype=torch.bfloat16))
+    want = torch.from_numpy(gold["denorm_on_bf16"]).permute(0, 1, 3, 4, 2).reshape(-1, C)
+    assert torch.equal(out.float().cpu(), want)
+
+
 def test_feature_norm_and_vq_kernels(cuda):
     from landiff_amd import ops
     g = torch.Generator().manual_seed(1)

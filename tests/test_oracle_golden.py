@@ -219,6 +219,29 @@ def test_titok_encoder_fp32():
     np.testing.assert_allclose(out[0].numpy(), ref.numpy(), rtol=0, atol=2e-5)
 
 
+def test_feature_norm_gate():
+    """norm_features / denorm_features act only when the config names a mean_std_path (video_titok_vq.py:221-233): with the
+    shipped config the checkpoint's mean/std buffers must NOT be applied.  Golden = the reference's own two methods run with
+    mean_std_path None / set on non-trivial statistics."""
+    import dataclasses
+    from landiff_amd.config import TokenizerConfig
+    from oracle.tokenizer import DetokenizerOracle, TokenizerEncoderOracle
+    g = load("feature_norm")
+    x, st = T(g["x"]), {"mean": T(g["mean"]), "std": T(g["std"])}
+    off = dataclasses.replace(TokenizerConfig.tiny(), out_channels=x.shape[2])
+    on = dataclasses.replace(off, norm_features=True)
+    assert not TokenizerConfig().norm_features                         # the shipped configuration
+    np.testing.assert_array_equal(TokenizerEncoderOracle(st, off, torch.float32).norm_features(x).numpy(), g["norm_off"])
+    np.testing.assert_array_equal(g["norm_off"], g["x"])
+    np.testing.assert_array_equal(TokenizerEncoderOracle(st, on, torch.float32).norm_features(x).numpy(), g["norm_on"])
+    xcl = x.permute(0, 1, 3, 4, 2)
+    cl = lambda a: np.transpose(a, (0, 1, 3, 4, 2))
+    np.testing.assert_array_equal(DetokenizerOracle(st, None, off, None, torch.float32).denorm_features(xcl).numpy(), cl(g["denorm_off"]))
+    np.testing.assert_array_equal(DetokenizerOracle(st, None, on, None, torch.float32).denorm_features(xcl).numpy(), cl(g["denorm_on"]))
+    out = DetokenizerOracle(st, None, on, None, torch.bfloat16).denorm_features(xcl.to(torch.bfloat16))
+    np.testing.assert_array_equal(out.float().numpy(), cl(g["denorm_on_bf16"]))
+
+
 def test_encoder_mask_closed_form_and_launch_labels():
     """VideoEncoderMask: scalar and vectorised restatements equal the reference's mask (tiny dense; full size by sha256
     and row counts), and the two-launch label scheme of the product (landiff_amd/tokenizer_encoder.py) reproduces it."""
