@@ -248,7 +248,7 @@ __device__ __forceinline__ void attn_pipe2_body(const AttnParams& p, int force_s
         PV(5); EXP2(1, 14); CVT2(3, 2);  KF(5); MAX4(m1, 1, 0); FENCE();
         PV(6); KF(6); MAX4(m1, 1, 4); MAX4(m1, 1, 8); FENCE();
         PV(7); KF(7); MAX4(m1, 1, 12); FENCE();
-        if (HAS_QK) rebase_if(sn, fmaxf(m0, m1), false);
+        if constexpr (!FAST && HAS_QK) rebase_if(sn, fmaxf(m0, m1), false);   // (FAST: no maximum exists -- keep the dead test out of the loop)
       }
       // ---- end of a period (odd iteration): retire this wave's LDS reads and DMA pieces, then the barrier.
       //      (the builtin, unlike inline asm, is visible to hipcc's own wait-count bookkeeping: no redundant waits follow)

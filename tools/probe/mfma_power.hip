@@ -1,0 +1,150 @@
+// What the matrix pipe sustains under the chip's power / current governor, per MFMA shape and operand source, with no
+// global-memory traffic at all: one wave per SIMD, a 128x128 fp32 accumulator tile per wave (256 registers), operands
+// from a small register pool (a new fragment set every k-step, K = 64 per pool cycle) or re-read from LDS every k-step.
+// Each variant runs ~1.5 s so that the clock settles; rocm-smi is sampled while the queue is still busy.
+// Build: hipcc --offload-arch=gfx950 -O3 -o mfma_power mfma_power.hip ; run: ./mfma_power [randn|zeros]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// VAR 0: v_mfma_f32_32x32x16_bf16, 4x4 accumulators, operands from a 4-set register pool
+// VAR 1: v_mfma_f32_16x16x32_bf16, 8x8 accumulators, operands from a 2-set register pool
+// VAR 2: as 0, operands re-read from LDS every k-step (8 ds_read_b128 per 16 MFMAs, as the GEMM main loop does)
+// VAR 3: as 1, operands re-read from LDS every k-step (16 ds_read_b128 per 64 MFMAs)
+// VAR 4: as 0 with the B fragment outermost (each B reused by 4 consecutive MFMAs instead of each A)
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void mfma_loop(const bf16x8* __restrict__ src, float* sink, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 65536 / 16; i += 256) ((bf16x8*)smem)[i] = src[(blockIdx.x * 4096 + i) % (1 << 16)];
+  __syncthreads();
+  const char* lbase = smem + wave * 16384 + lane * 16;
+  float total = 0.f;
+  if constexpr (VAR == 0 || VAR == 2 || VAR == 4) {
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 a[4][4], b[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[p][i] = src[((p * 8 + i) * 256 + tid) % (1 << 16)]; b[p][i] = src[((p * 8 + 4 + i) * 256 + tid + 7777) % (1 << 16)]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if constexpr (VAR == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            a[p][i] = *(const bf16x8*)(lbase + ((p * 8 + i) & 15) * 1024);
+            b[p][i] = *(const bf16x8*)(lbase + ((p * 8 + 4 + i) & 15) * 1024);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (VAR == 4) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[p][j], b[p][i], acc[j][i], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[p][i], b[p][j], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) total += acc[i][j][r];
+  } else {
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    bf16x8 a[2][8], b[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { a[p][i] = src[((p * 16 + i) * 256 + tid) % (1 << 16)]; b[p][i] = src[((p * 16 + 8 + i) * 256 + tid + 7777) % (1 << 16)]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        if constexpr (VAR == 3) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            a[p][i] = *(const bf16x8*)(lbase + ((p * 16 + i) & 15) * 1024);
+            b[p][i] = *(const bf16x8*)(lbase + ((p * 16 + 8 + i) & 15) * 1024);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][i], b[p][j], acc[i][j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) total += acc[i][j][r];
+  }
+  if (total == 1234.5678f) sink[tid] = total;
+}
+
+template <int VAR>
+void run(const char* name, const bf16x8* src, float* sink) {
+  const int iters = 2000, wgs = 256 * 4;
+  hipFuncSetAttribute((const void*)mfma_loop<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  const double flop_launch = (double)wgs * 4 * iters * 2.0 * 128 * 128 * 64;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) mfma_loop<VAR><<<wgs, 256, 65536>>>(src, sink, iters);
+  hipDeviceSynchronize();
+  // find the launch count for ~1.5 s
+  hipEventRecord(e0); mfma_loop<VAR><<<wgs, 256, 65536>>>(src, sink, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms1; hipEventElapsedTime(&ms1, e0, e1);
+  const int n = (int)(1500.f / ms1) + 1;
+  hipEventRecord(e0);
+  for (int i = 0; i < n; ++i) mfma_loop<VAR><<<wgs, 256, 65536>>>(src, sink, iters);
+  hipEventRecord(e1);
+  char cmd[256];
+  snprintf(cmd, sizeof cmd, "sleep 0.9; rocm-smi --showpower --showclocks 2>/dev/null | grep -E 'sclk|Package Power' | sed 's/^/      /'");
+  if (system(cmd)) {}
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("%-58s %7.3f ms/launch  %6.0f TFLOP/s\n", name, ms / n, flop_launch * n / (ms * 1e-3) / 1e12);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const bool zeros = argc > 1 && !strcmp(argv[1], "zeros");
+  std::vector<unsigned short> h((size_t)(1 << 16) * 8);
+  srand(1);
+  for (auto& x : h) {
+    float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = rand() / (float)RAND_MAX;
+    float g = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2) * 0.05f;          // small enough that 2000 x 64-deep sums stay finite
+    unsigned bits; memcpy(&bits, &g, 4);
+    x = zeros ? 0 : (unsigned short)(bits >> 16);
+  }
+  bf16x8* src; float* sink;
+  hipMalloc(&src, h.size() * 2); hipMalloc(&sink, 4096);
+  hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  printf("operands: %s\n", zeros ? "zeros" : "randn * 0.05");
+  run<0>("32x32x16, register operands (A reused 4x)", src, sink);
+  run<4>("32x32x16, register operands (B reused 4x)", src, sink);
+  run<1>("16x16x32, register operands", src, sink);
+  run<2>("32x32x16, operands from LDS (8 ds_read_b128 / 16 MFMA)", src, sink);
+  run<3>("16x16x32, operands from LDS (16 ds_read_b128 / 64 MFMA)", src, sink);
+  return 0;
+}
