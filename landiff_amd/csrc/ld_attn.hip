@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
 }  // namespace
 
 int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st);   // ld_attn_pipe.hip
+int ld_attn_p16_launch(const AttnParams& p, hipStream_t st);     // ld_attn_p16.hip
 
 // name of the kernel the calling thread's last ld_attn_fwd_bf16 launched (bench.py labels its roofline object with it)
 static thread_local const char* g_attn_last_kernel = "";
@@ -367,8 +368,9 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   dim3 grid((unsigned)(B * H * nqb)), block(256);
   static int var = -1;
   if (var < 0) {
-    // tuning knob: 0 = default (pipelined kernel of ld_attn_pipe.hip where it applies, else the plain kernel),
-    // 9 = plain kernel everywhere, 1 / 4 = plain kernel with row sums on the matrix pipe / lean-register 4-waves form
+    // tuning knob: 0 = default (pipelined 16x16x32 kernel of ld_attn_p16.hip where it applies, else the plain kernel),
+    // 8 = the pipelined 32x32x16 kernel of ld_attn_pipe.hip (round-1 default), 9 = plain kernel everywhere,
+    // 1 / 4 = plain kernel with row sums on the matrix pipe / lean-register 4-waves form
     const char* e = getenv("LD_ATTN_VARIANT");
     var = e ? atoi(e) : 0;
   }
@@ -376,7 +378,7 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   const size_t s1 = 2 * STAGE_BYTES + 64;
   const int64_t nkt = (Nk + KT - 1) / KT;
   if ((var == 0 || var == 8) && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {
-    return ld_attn_pipe2_launch(p, st);
+    return var == 0 ? ld_attn_p16_launch(p, st) : ld_attn_pipe2_launch(p, st);
   } else if (var == 1) {
     g_attn_last_kernel = "ld_attn_kernel<1,true,false,true,2>";
     hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);

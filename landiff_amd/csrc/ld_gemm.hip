@@ -167,22 +167,13 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, float (&v)[
 // requested before its accumulators are staged); everything else takes the compact generic path.
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE = 2, EPI_GENERIC = 3, EPI_GELU_MX = 4 };   // 4: bias + GELU, MXFP8 output
 
-template <int MI, int NI, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], char* smem, int wave, int lane,
-                                              int row0, int col0w) {
-  float* cw = (float*)smem + wave * (32 * CW_STRIDE);
+// stage_block(ic) writes the 32 x 64 fp32 values of 32-row block ic of the wave tile into cw[32][CW_STRIDE] -- the only part
+// that depends on the MFMA shape the accumulators came from (gemm_epilogue: 32x32x16, gemm_epilogue16: 16x16x32).
+template <int MI, int EPI, typename StageFn>
+__device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&& stage_block, float* cw, int lane,
+                                                   int row0, int col0w) {
   const int col0 = (lane & 7) * 8;
   const int gn0 = col0w + col0;
-  auto stage_block = [&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        cw[row * CW_STRIDE + j * 32 + (lane & 31)] = acc[i][j][r];
-      }
-  };
   if constexpr (EPI == EPI_GENERIC) {
     const bool vec_ok = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) &&
                         (p.resid == nullptr || (p.ldr & 7) == 0) &&
@@ -310,6 +301,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   static_assert(MI <= 4, "extend the expansion");
 }
 
+template <int MI, int NI, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], char* smem, int wave, int lane,
+                                              int row0, int col0w) {
+  float* cw = (float*)smem + wave * (32 * CW_STRIDE);
+  auto stage_block = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        cw[row * CW_STRIDE + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+  };
+  gemm_epilogue_core<MI, EPI>(p, stage_block, cw, lane, row0, col0w);
+}
+
+// Accumulators of v_mfma_f32_16x16x32_bf16: acc[i][j][r] = C[i * 16 + (lane >> 4) * 4 + r][j * 16 + (lane & 15)], a wave tile of
+// (MI * 32) rows x 64 columns = [2 * MI][4] blocks starting at column block j0.
+template <int MI, int EPI, int NJ>
+__device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&acc)[2 * MI][NJ], int j0, char* smem, int wave,
+                                                int lane, int row0, int col0w) {
+  float* cw = (float*)smem + wave * (32 * CW_STRIDE);
+  auto stage_block = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cw[(di * 16 + (lane >> 4) * 4 + r) * CW_STRIDE + j * 16 + (lane & 15)] = acc[2 * i + di][j0 + j][r];
+  };
+  gemm_epilogue_core<MI, EPI>(p, stage_block, cw, lane, row0, col0w);
+}
+
 // which specialisation a problem may use (the generic path handles everything)
 inline int pick_epilogue(const GemmParams& p) {
   if (p.mx_out) return EPI_GELU_MX;      // (the launcher checked: bias + GELU-tanh only, N % 32 == 0)
@@ -325,7 +352,11 @@ inline int pick_epilogue(const GemmParams& p) {
 }
 
 // Block tile BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN) = MI x NI MFMA 32x32 tiles.
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int EPI>
+// M16: the same tiles on v_mfma_f32_16x16x32_bf16 (32-deep k-steps, [2 * MI][4] accumulators of 4 registers): equal FLOPs per
+// register and per LDS byte, but the 16x16x32 form draws less power per FLOP on random operands -- under the chip's power
+// governor an MFMA-only loop sustains 2105 TFLOP/s on it against 1837 on 32x32x16 (tools/probe/mfma_power.hip,
+// profiles/r02_mfma_power_probe.txt) -- and power, not issue slots, is what bounds these kernels.
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int EPI, bool M16 = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
@@ -399,18 +430,39 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
     for (int i = 0; i < B_LOADS; ++i) glds16(p.W + offW[i] + koffW, base + A_BYTES + (wave * B_LOADS + i) * 1024);
   };
 
-  f32x16_t acc[MI][NI];
+  f32x16_t acc[M16 ? 1 : MI][M16 ? 1 : NI];
+  f32x4_t acc16[M16 ? 2 * MI : 1][M16 ? 4 : 1];
+  if constexpr (M16) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 
   // fragment read offsets: row * 128 B plus the swizzled 16-B chunk of k-step kk (rows of later MFMA tiles are
-  // +32 rows = +4096 B with the same swizzle key, so they fold into the ds_read immediate offset)
+  // +32 rows = +4096 B (16x16x32: +16 rows = +2048 B) with the same swizzle key, so they fold into the ds_read immediate
+  // offset).  16x16x32 operand: lane l holds row l & 15, k = (l >> 4) * 8 .. + 8 of the 32-deep step: the 16-byte chunk
+  // ks * 4 + (l >> 4); with the (row >> 1) & 7 XOR the four 16-lane groups of a ds_read_b128 each cover all 64 banks.
   int rdA[4], rdB[4];
-  {
+  if constexpr (M16) {
+    const int ra = wr * (BM / WM) + (lane & 15), rb = wc * (BN / WN) + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 4 + (lane >> 4);
+      rdA[ks] = ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4);
+      rdB[ks] = A_BYTES + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4);
+    }
+    rdA[2] = rdA[3] = rdB[2] = rdB[3] = 0;
+  } else {
     const int ra = wr * (BM / WM) + (lane & 31), rb = wc * (BN / WN) + (lane & 31);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -425,27 +477,53 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   // the 128-register accumulator tile of the 256x256 configuration.
   auto compute = [&](auto bufc) {
     constexpr int OFF = decltype(bufc)::value * STAGE;
-    bf16x8_t a[2][MI], b[2][NI];
+    if constexpr (M16) {
+      // B fragments of both k-steps up front; A fragments single-buffered: block i's k-step-1 fragment is requested right
+      // after its four k-step-0 MFMAs (2 * MI - 1 blocks of MFMAs of cover), which keeps the fragment registers at
+      // (2 * MI + 8) x 4 next to the accumulators
+      bf16x8_t a[2 * MI], b[2][4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) a[0][i] = *(const bf16x8_t*)(smem + rdA[0] + OFF + i * 4096);
+      for (int j = 0; j < 4; ++j) b[0][j] = *(const bf16x8_t*)(smem + rdB[0] + OFF + j * 2048);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) b[0][j] = *(const bf16x8_t*)(smem + rdB[0] + OFF + j * 4096);
+      for (int i = 0; i < 2 * MI; ++i) a[i] = *(const bf16x8_t*)(smem + rdA[0] + OFF + i * 2048);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      constexpr int dummy = 0; (void)dummy;
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk < 3) {
+      for (int j = 0; j < 4; ++j) b[1][j] = *(const bf16x8_t*)(smem + rdB[1] + OFF + j * 2048);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[nxt][i] = *(const bf16x8_t*)(smem + rdA[kk + 1] + OFF + i * 4096);
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) b[nxt][j] = *(const bf16x8_t*)(smem + rdB[kk + 1] + OFF + j * 4096);
+        for (int i = 0; i < 2 * MI; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[ks][j], acc16[i][j], 0, 0, 0);
+          if (ks == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            a[i] = *(const bf16x8_t*)(smem + rdA[1] + OFF + i * 2048);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+    } else {
+      bf16x8_t a[2][MI], b[2][NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i) a[0][i] = *(const bf16x8_t*)(smem + rdA[0] + OFF + i * 4096);
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-      if (MI * NI > 4) __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < NI; ++j) b[0][j] = *(const bf16x8_t*)(smem + rdB[0] + OFF + j * 4096);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk < 3) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) a[nxt][i] = *(const bf16x8_t*)(smem + rdA[kk + 1] + OFF + i * 4096);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) b[nxt][j] = *(const bf16x8_t*)(smem + rdB[kk + 1] + OFF + j * 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        if (MI * NI > 4) __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
@@ -493,7 +571,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   }
   __syncthreads();
 
-  gemm_epilogue<MI, NI, EPI>(p, acc, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
+  if constexpr (M16) gemm_epilogue16<MI, EPI>(p, acc16, 0, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
+  else gemm_epilogue<MI, NI, EPI>(p, acc, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1193,6 +1272,24 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
   const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   dim3 grid(nbm * nbn), block(NW * 64);
   const int epi = pick_epilogue(p);
+  // 16x16x32 MFMAs by default (LD_GEMM_M16=0: the 32x32x16 form, kept for A/B measurements): +7...11 % on the DiT shapes
+  static int m16 = -1;
+  if (m16 < 0) { const char* e = getenv("LD_GEMM_M16"); m16 = e ? atoi(e) : 1; }
+#define LD_GEMM_LAUNCH16(CONV_, EPI_) \
+  return launch_kernel<ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, CONV_, EPI_, true>>("ld_gemm16", grid, block, SMEM, stream, p)
+  if (m16) {
+    if (conv) {
+      if (epi == EPI_BIAS) LD_GEMM_LAUNCH16(true, EPI_BIAS);
+      LD_GEMM_LAUNCH16(true, EPI_GENERIC);
+    }
+    switch (epi) {
+      case EPI_BIAS: LD_GEMM_LAUNCH16(false, EPI_BIAS);
+      case EPI_GELU: LD_GEMM_LAUNCH16(false, EPI_GELU);
+      case EPI_GATE: LD_GEMM_LAUNCH16(false, EPI_GATE);
+      default: LD_GEMM_LAUNCH16(false, EPI_GENERIC);
+    }
+  }
+#undef LD_GEMM_LAUNCH16
 #define LD_GEMM_LAUNCH(CONV_, EPI_) \
   return launch_kernel<ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, CONV_, EPI_>>("ld_gemm", grid, block, SMEM, stream, p)
   if (conv) {
@@ -1267,9 +1364,9 @@ int launch_w4r(const GemmParams& p, hipStream_t stream) {
 }
 
 int launch(const GemmParams& p, bool conv, hipStream_t stream) {
-  // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves, 3 = 256x256 / 8 waves (both 2-stage, barrier-drained),
-  // 7 = 256x256 / 8 waves ping-pong main loop, 8 = 4 waves LDS-DMA pipelined, 11 = 4 waves register-staged (default
-  // for large problems when the knob is unset)
+  // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves, 3 = 256x256 / 8 waves (both 2-stage, barrier-drained, 16x16x32 MFMAs
+  // unless LD_GEMM_M16=0; 3 is the default for large problems when the knob is unset), 7 = 256x256 / 8 waves ping-pong main
+  // loop, 8 = 4 waves LDS-DMA pipelined, 11 = 4 waves register-staged (7 / 8 / 11: 32x32x16 MFMAs, round-1 experiments)
   static int forced = -1, group_m = 8;
   if (forced < 0) {
     const char* e = getenv("LD_GEMM_TILE"); forced = e ? atoi(e) : 0;
@@ -1291,7 +1388,10 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
   if (cfg != 3 && cfg != 7 && cfg != 8 && cfg != 11) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
   // default for the large linear layers: the register-staged 4-wave loop (qkv / 4h / 4h->h GEMMs 3-6 % faster than the
   // 8-wave kernel); the gated-residual epilogue on a short K (DiT proj, K = 1920) hides its operand loads better with 8 waves
-  const bool w4r_default = forced == 0 && pp_ok && !conv && !(pick_epilogue(p) == EPI_GATE && p.K < 4096);
+  // (round 1 default for the large linear layers: the register-staged 4-wave loop on 32x32x16 MFMAs, LD_GEMM_TILE=11; the
+  //  8-wave LDS-DMA kernel on 16x16x32 MFMAs is 3-8 % faster than it on all four DiT shapes: both are bound by the power
+  //  governor, and the 16x16x32 form costs less energy per FLOP)
+  const bool w4r_default = false;
   auto big = [&](const GemmParams& q) {
     if ((cfg == 11 || w4r_default) && pp_ok && !conv) return launch_w4r(q, stream);
     if (cfg == 8 && pp_ok) return launch_w4(q, conv, stream);
