@@ -32,7 +32,12 @@ namespace {
 
 __device__ __forceinline__ int swz_k(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
 
-template <int NW>     // waves per workgroup (32 query rows each)
+// MSUM: softmax denominators from the matrix pipe -- l[qb] += ones(16 x 32) . P[kg][qb], 4 more MFMAs per tile (+12.5 %)
+// instead of 32 v_add_f32: the kernel's cycle count follows its VALU-class issue count (SQ counters, profiles/
+// r02_attn_p16_pmc_sq.txt), and this takes it from 112 to 84 per tile.  Every lane then holds the complete denominator of
+// its two query rows (all 16 result rows of the all-ones product are equal): no cross-lane reduction at the end.  The sum
+// runs over the bf16-rounded probabilities, i.e. exactly the weights the PV product uses.
+template <int NW, bool MSUM>     // NW: waves per workgroup (32 query rows each)
 __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_safe, char* smem) {   // smem: K slots 0..3 | V^T slots 0..3 | NW flag words
   constexpr int VBASE = 4 * KTILE_BYTES;
   const int tid = threadIdx.x;
@@ -149,15 +154,21 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
   // returns the two softmax denominators of this lane's query rows (complete: summed over the four lanes of a row)
   float ltot[2] = {0.f, 0.f};
   auto fast_pass = [&]() {
-    float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // [qb][two partial sums]
+    float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // !MSUM: [qb][two partial sums]
+    f32x4_t lacc[2] = {zero4, zero4};               // MSUM: row sums from the matrix pipe
+    const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 #pragma unroll
     for (int db = 0; db < 4; ++db) { o[db][0] = zero4; o[db][1] = zero4; }
     f32x4_t sA[4][2], sB[4][2];
     bf16x8_t kf[4][2], vf[4][2];
+    // the 32 scores of a lane in a tile are numbered v = kb*8 + qb*4 + r (v < 16: key group 0, v >= 16: key group 1)
+    auto EXPV = [&](f32x4_t (&s)[4][2], int v) { const int kb = v >> 3, qb = (v >> 2) & 1, r = v & 3; s[kb][qb][r] = __builtin_amdgcn_exp2f(s[kb][qb][r]); };
+    constexpr int NPRE = MSUM ? 18 : 0;             // MSUM: scores 0..NPRE-1 of tile j+1 are exponentiated under the PV MFMAs of tile j
 
-    // One pipelined iteration.  sc = S_j (finished scores), sn receives S_{j+1}.  HAS_QK: tile j+1 exists; HAS_K2: tile j+2
-    // exists (a main-loop iteration); MASK: tile j+1 is the ragged one.  Even main-loop iterations issue the period's DMA
-    // pieces (past the end the tile index is clamped: a re-fetch into a slot nobody reads); odd iterations end the period.
+    // One pipelined iteration.  sc = S_j (finished scores; MSUM: the first NPRE already probabilities), sn receives S_{j+1}.
+    // HAS_QK: tile j+1 exists; HAS_K2: tile j+2 exists (a main-loop iteration); MASK: tile j+1 is the ragged one.  Even
+    // main-loop iterations issue the period's DMA pieces (past the end the tile index is clamped: a re-fetch into a slot nobody
+    // reads); odd iterations end the period.
     auto iter = [&](f32x4_t (&sc)[4][2], f32x4_t (&sn)[4][2], int j, auto vslot_c, auto has_qk_c, auto has_k2_c, auto mask_c) {
       constexpr int vslot = decltype(vslot_c)::value;            // slot of V_j; the others follow from it
       constexpr int k2slot = (vslot + 2) & 3;
@@ -168,9 +179,10 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
       dt0 = dt0 < n ? dt0 : n - 1; dt1 = dt1 < n ? dt1 : n - 1;
       const int dslot0 = kwave ? vslot : (vslot + 2) & 3, dslot1 = kwave ? (vslot + 1) & 3 : (vslot + 3) & 3;
       u32x4_t pw[2][2];                                          // P fragments [kg][qb]
-      // the 32 scores of a lane are numbered v = kb*8 + qb*4 + r; E(v): score -> probability; A(v): row-sum add; C(kg, qb, half):
-      // two packed words of P fragment [kg][qb]
-      auto E = [&](int v) { const int kb = v >> 3, qb = (v >> 2) & 1, r = v & 3; sc[kb][qb][r] = __builtin_amdgcn_exp2f(sc[kb][qb][r]); };
+      // E(v): score -> probability (tile j); N(v): the same on tile j+1 (MSUM); A(v): row-sum add (!MSUM); C(kg, qb, half): two
+      // packed words of P fragment [kg][qb]
+      auto E = [&](int v) { EXPV(sc, v); };
+      auto N = [&](int v) { if (HAS_QK) EXPV(sn, v); };
       auto A = [&](int v) { const int kb = v >> 3, qb = (v >> 2) & 1, r = v & 3; ls[qb][r & 1] += sc[kb][qb][r]; };
       auto C = [&](int kg, int qb, int half) {
         pw[kg][qb][2 * half] = pack_bf16x2(sc[2 * kg + half][qb][0], sc[2 * kg + half][qb][1]);
@@ -188,46 +200,93 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
         const int kg = g >> 3, db = (g >> 1) & 3, qb = g & 1;
         o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[db][kg], __builtin_bit_cast(bf16x8_t, pw[kg][qb]), o[db][qb], 0, 0, 0);
       };
+      auto SUM = [&](int kg, int qb) {
+        lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8_t, pw[kg][qb]), lacc[qb], 0, 0, 0);
+      };
       auto DMA = [&](int g) {                 // piece g of the period's 2 * NPW
         if (do_dma && g < 2 * NPW) dma_piece(g % NPW, g < NPW ? dslot0 : dslot1, g < NPW ? dt0 : dt1);
       };
-      // ---- phase 1: QK^T of tile j+1 (16 MFMAs) over exp2 of the key groups kg = 0 (all 16 scores: v = 0..15) and half of
-      //      kg = 1 (v = 16..23), the packing of P[0][*], the V_j fragment reads and the period's DMA pieces ----
-      QK(0);  E(0);  E(1);  VF(0); DMA(0); FENCE();
-      QK(1);  E(2);  E(3);  A(0);  FENCE();
-      QK(2);  E(4);  E(5);  VF(1); DMA(1); FENCE();
-      QK(3);  E(6);  E(7);  A(1);  FENCE();
-      QK(4);  E(8);  E(9);  VF(2); DMA(2); FENCE();
-      QK(5);  E(10); E(11); C(0, 0, 0); FENCE();
-      QK(6);  E(12); E(13); VF(3); DMA(3); FENCE();
-      QK(7);  E(14); E(15); C(0, 1, 0); FENCE();
-      QK(8);  E(16); A(2);  VF(4); DMA(4); FENCE();
-      QK(9);  E(17); C(0, 0, 1); FENCE();
-      QK(10); E(18); A(3);  VF(5); DMA(5); FENCE();
-      QK(11); E(19); C(0, 1, 1); FENCE();
-      QK(12); E(20); A(4);  VF(6); DMA(6); FENCE();
-      QK(13); E(21); A(5);  FENCE();
-      QK(14); E(22); A(6);  VF(7); DMA(7); FENCE();
-      QK(15); E(23); A(7);  FENCE();
-      if (MASK) mask_tail(sn, j + 1);
-      // ---- phase 2a: PV over key group 0 (8 MFMAs) over the rest of exp2 (v = 24..31) and the packing of P[1][*] ----
-      PV(0);  E(24); E(25); A(8);  FENCE();
-      PV(1);  E(26); E(27); C(1, 0, 0); FENCE();
-      PV(2);  E(28); E(29); A(9);  FENCE();
-      PV(3);  E(30); E(31); C(1, 1, 0); FENCE();
-      PV(4);  A(10); A(11); KF(0); FENCE();
-      PV(5);  C(1, 0, 1);   A(12); FENCE();
-      PV(6);  A(13); A(14); KF(1); FENCE();
-      PV(7);  C(1, 1, 1);   A(15); FENCE();
-      // ---- phase 2b: PV over key group 1 (8 MFMAs) over the remaining row-sum adds and the K_{j+2} fragment reads ----
-      PV(8);  A(16); A(17); KF(2); FENCE();
-      PV(9);  A(18); A(19); FENCE();
-      PV(10); A(20); A(21); KF(3); FENCE();
-      PV(11); A(22); A(23); FENCE();
-      PV(12); A(24); A(25); KF(4); FENCE();
-      PV(13); A(26); A(27); KF(5); FENCE();
-      PV(14); A(28); A(29); KF(6); FENCE();
-      PV(15); A(30); A(31); KF(7); FENCE();
+      if constexpr (MSUM) {
+        // ---- phase 1: QK^T of tile j+1 (16 MFMAs) over exp2 of scores 18..31 of tile j, the packing of P[0][*], the V_j
+        //      fragment reads and the period's DMA pieces ----
+        QK(0);  E(18); C(0, 0, 0); VF(0); DMA(0); FENCE();
+        QK(1);  E(19); FENCE();
+        QK(2);  E(20); C(0, 1, 0); VF(1); DMA(1); FENCE();
+        QK(3);  E(21); FENCE();
+        QK(4);  E(22); C(0, 0, 1); VF(2); DMA(2); FENCE();
+        QK(5);  E(23); FENCE();
+        QK(6);  E(24); C(0, 1, 1); VF(3); DMA(3); FENCE();
+        QK(7);  E(25); FENCE();
+        QK(8);  E(26); VF(4); DMA(4); FENCE();
+        QK(9);  E(27); FENCE();
+        QK(10); E(28); VF(5); DMA(5); FENCE();
+        QK(11); E(29); FENCE();
+        QK(12); E(30); VF(6); DMA(6); FENCE();
+        QK(13); E(31); FENCE();
+        QK(14); C(1, 0, 0); VF(7); DMA(7); FENCE();
+        QK(15); C(1, 1, 0); FENCE();
+        if (MASK) mask_tail(sn, j + 1);
+        // ---- phase 2a: PV and row sums over key group 0 (10 MFMAs) over the packing of P[1][*] and the first exp2 of tile j+1 ----
+        PV(0);  C(1, 0, 1); FENCE();
+        PV(1);  C(1, 1, 1); FENCE();
+        PV(2);  N(0);  KF(0); FENCE();
+        PV(3);  N(1);  FENCE();
+        PV(4);  N(2);  KF(1); FENCE();
+        PV(5);  N(3);  FENCE();
+        PV(6);  N(4);  KF(2); FENCE();
+        PV(7);  N(5);  FENCE();
+        SUM(0, 0); N(6); KF(3); FENCE();
+        SUM(0, 1); N(7); FENCE();
+        // ---- phase 2b: PV and row sums over key group 1 (10 MFMAs) over exp2 of scores 8..17 of tile j+1 and the K_{j+2} reads ----
+        PV(8);  N(8);  KF(4); FENCE();
+        PV(9);  N(9);  FENCE();
+        PV(10); N(10); KF(5); FENCE();
+        PV(11); N(11); FENCE();
+        PV(12); N(12); KF(6); FENCE();
+        PV(13); N(13); FENCE();
+        PV(14); N(14); KF(7); FENCE();
+        PV(15); N(15); FENCE();
+        SUM(1, 0); N(16); FENCE();
+        SUM(1, 1); N(17); FENCE();
+      } else {
+        // ---- phase 1: QK^T of tile j+1 (16 MFMAs) over exp2 of the key groups kg = 0 (all 16 scores: v = 0..15) and half of
+        //      kg = 1 (v = 16..23), the packing of P[0][*], the V_j fragment reads and the period's DMA pieces ----
+        QK(0);  E(0);  E(1);  VF(0); DMA(0); FENCE();
+        QK(1);  E(2);  E(3);  A(0);  FENCE();
+        QK(2);  E(4);  E(5);  VF(1); DMA(1); FENCE();
+        QK(3);  E(6);  E(7);  A(1);  FENCE();
+        QK(4);  E(8);  E(9);  VF(2); DMA(2); FENCE();
+        QK(5);  E(10); E(11); C(0, 0, 0); FENCE();
+        QK(6);  E(12); E(13); VF(3); DMA(3); FENCE();
+        QK(7);  E(14); E(15); C(0, 1, 0); FENCE();
+        QK(8);  E(16); A(2);  VF(4); DMA(4); FENCE();
+        QK(9);  E(17); C(0, 0, 1); FENCE();
+        QK(10); E(18); A(3);  VF(5); DMA(5); FENCE();
+        QK(11); E(19); C(0, 1, 1); FENCE();
+        QK(12); E(20); A(4);  VF(6); DMA(6); FENCE();
+        QK(13); E(21); A(5);  FENCE();
+        QK(14); E(22); A(6);  VF(7); DMA(7); FENCE();
+        QK(15); E(23); A(7);  FENCE();
+        if (MASK) mask_tail(sn, j + 1);
+        // ---- phase 2a: PV over key group 0 (8 MFMAs) over the rest of exp2 (v = 24..31) and the packing of P[1][*] ----
+        PV(0);  E(24); E(25); A(8);  FENCE();
+        PV(1);  E(26); E(27); C(1, 0, 0); FENCE();
+        PV(2);  E(28); E(29); A(9);  FENCE();
+        PV(3);  E(30); E(31); C(1, 1, 0); FENCE();
+        PV(4);  A(10); A(11); KF(0); FENCE();
+        PV(5);  C(1, 0, 1);   A(12); FENCE();
+        PV(6);  A(13); A(14); KF(1); FENCE();
+        PV(7);  C(1, 1, 1);   A(15); FENCE();
+        // ---- phase 2b: PV over key group 1 (8 MFMAs) over the remaining row-sum adds and the K_{j+2} fragment reads ----
+        PV(8);  A(16); A(17); KF(2); FENCE();
+        PV(9);  A(18); A(19); FENCE();
+        PV(10); A(20); A(21); KF(3); FENCE();
+        PV(11); A(22); A(23); FENCE();
+        PV(12); A(24); A(25); KF(4); FENCE();
+        PV(13); A(26); A(27); KF(5); FENCE();
+        PV(14); A(28); A(29); KF(6); FENCE();
+        PV(15); A(30); A(31); KF(7); FENCE();
+      }
       // ---- end of a period (odd iteration): retire this wave's LDS reads and DMA pieces, then the barrier ----
       if (!EVEN) {
         __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
@@ -246,6 +305,8 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
     qk_tile(sA, kf);
     FENCE();
     load_kf(kf, 1);
+#pragma unroll
+    for (int v = 0; v < NPRE; ++v) EXPV(sA, v);
     __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();        // every wave has K0 / K1 in registers: period 0 may refill their slots
     FENCE();
@@ -264,10 +325,14 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
     iter(sB, sA, j + 1, S1{}, F{}, F{}, F{});
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      float l = ls[qb][0] + ls[qb][1];
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
-      ltot[qb] = l;
+      if constexpr (MSUM) {
+        ltot[qb] = lacc[qb][0];
+      } else {
+        float l = ls[qb][0] + ls[qb][1];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        ltot[qb] = l;
+      }
     }
   };
 
@@ -368,22 +433,46 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
 
 __global__ __launch_bounds__(256, 2) void ld_attn_p16_w4_kernel(AttnParams p, int force_safe) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  attn_p16_body<4>(p, force_safe, smem);
+  attn_p16_body<4, true>(p, force_safe, smem);
+}
+__global__ __launch_bounds__(512, 2) void ld_attn_p16_w8_kernel(AttnParams p, int force_safe) {       // 256 query rows per workgroup
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_p16_body<8, true>(p, force_safe, smem);
+}
+__global__ __launch_bounds__(256, 2) void ld_attn_p16a_w4_kernel(AttnParams p, int force_safe) {      // row sums by v_add_f32 (A/B timing)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_p16_body<4, false>(p, force_safe, smem);
 }
 
 }  // namespace
 
 void ld_attn_set_last_kernel(const char* name);   // ld_attn.hip
 
-// LD_ATTN_SAFE=1 forces the running-max pass (testing).
+// LD_ATTN_SAFE=1 forces the running-max pass (testing); LD_ATTN_MSUM=0 takes the row sums by v_add_f32 (A/B timing).
 int ld_attn_p16_launch(const AttnParams& p, hipStream_t st) {
   constexpr int SMEM = 8 * KTILE_BYTES + 64;
-  static int safe = -1;
-  if (safe < 0) { const char* e = getenv("LD_ATTN_SAFE"); safe = e ? atoi(e) : 0; }
-  static thread_local LdSmemCache c4{};
-  if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_p16_w4_kernel, SMEM, &c4)) return rc;
+  static int safe = -1, msum = 1, nw = 4;
+  if (safe < 0) {
+    const char* e = getenv("LD_ATTN_SAFE"); safe = e ? atoi(e) : 0;
+    const char* m = getenv("LD_ATTN_MSUM"); if (m) msum = atoi(m);
+    const char* w = getenv("LD_ATTN_NW"); if (w && atoi(w) == 8) nw = 8;
+  }
+  static thread_local LdSmemCache c4{}, c4a{}, c8{};
+  if (nw == 8 && msum) {
+    if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_p16_w8_kernel, SMEM, &c8)) return rc;
+    ld_attn_set_last_kernel(safe ? "ld_attn_p16_w8_kernel[safe pass forced]" : "ld_attn_p16_w8_kernel");
+    hipLaunchKernelGGL(ld_attn_p16_w8_kernel, dim3((unsigned)((long)p.B * p.H * ((p.Npad + 255) / 256))), dim3(512), SMEM, st, p, safe);
+    return ld_check_launch("ld_attn_fwd_bf16(p16 w8)");
+  }
+  if (int rc = msum ? ld_ensure_dyn_smem((const void*)ld_attn_p16_w4_kernel, SMEM, &c4)
+                    : ld_ensure_dyn_smem((const void*)ld_attn_p16a_w4_kernel, SMEM, &c4a)) return rc;
   dim3 grid((unsigned)((long)p.B * p.H * ((p.Npad + 127) / 128)));
-  ld_attn_set_last_kernel(safe ? "ld_attn_p16_w4_kernel[safe pass forced]" : "ld_attn_p16_w4_kernel");
-  hipLaunchKernelGGL(ld_attn_p16_w4_kernel, grid, dim3(256), SMEM, st, p, safe);
+  if (msum) {
+    ld_attn_set_last_kernel(safe ? "ld_attn_p16_w4_kernel[safe pass forced]" : "ld_attn_p16_w4_kernel");
+    hipLaunchKernelGGL(ld_attn_p16_w4_kernel, grid, dim3(256), SMEM, st, p, safe);
+  } else {
+    ld_attn_set_last_kernel(safe ? "ld_attn_p16a_w4_kernel[safe pass forced]" : "ld_attn_p16a_w4_kernel");
+    hipLaunchKernelGGL(ld_attn_p16a_w4_kernel, grid, dim3(256), SMEM, st, p, safe);
+  }
   return ld_check_launch("ld_attn_fwd_bf16(p16)");
 }
