@@ -475,8 +475,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   // One K-tile of MFMAs.  Fragments are software pipelined by hand (k-step kk+1 is requested before the MFMAs of kk)
   // and a scheduling barrier after every k-step keeps hipcc from hoisting all 4 k-steps' loads at once, which spills
   // the 128-register accumulator tile of the 256x256 configuration.
+  // a wave whose 64 output columns lie entirely past N (the half-empty last tile column of the N = 1920 shapes) issues no
+  // MFMAs: its accumulators stay zero and are never stored; the tile takes as long, at half the energy
+  const bool wave_live = n0 + wc * (BN / WN) < p.N;
   auto compute = [&](auto bufc) {
     constexpr int OFF = decltype(bufc)::value * STAGE;
+    if (!wave_live) return;
     if constexpr (M16) {
       // B fragments of both k-steps up front; A fragments single-buffered: block i's k-step-1 fragment is requested right
       // after its four k-step-0 MFMAs (2 * MI - 1 blocks of MFMAs of cover), which keeps the fragment registers at
