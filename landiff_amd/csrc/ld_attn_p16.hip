@@ -37,7 +37,9 @@ __device__ __forceinline__ int swz_k(int r) { return ((r >> 1) & 1) | (((r >> 3)
 // r02_attn_p16_pmc_sq.txt), and this takes it from 112 to 84 per tile.  Every lane then holds the complete denominator of
 // its two query rows (all 16 result rows of the all-ones product are equal): no cross-lane reduction at the end.  The sum
 // runs over the bf16-rounded probabilities, i.e. exactly the weights the PV product uses.  (Measured on one box: 3.99 ms with
-// the matrix-pipe sums, 4.10 ms with v_dot2_f32_bf16 on the packed P words, 4.29 ms with v_add_f32.)
+// the matrix-pipe sums, 4.10 ms with v_dot2_f32_bf16 on the packed P words, 4.29 ms with v_add_f32; on another, 4.05 ms
+// against 4.16 ms for key group 0 on the matrix pipe and key group 1 by v_add_f32: VALU issue slots are the scarcer resource
+// even with the matrix pipe 83 % busy.)
 template <int NW, bool MSUM>     // NW: waves per workgroup (32 query rows each)
 __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_safe, char* smem) {   // smem: K slots 0..3 | V^T slots 0..3 | NW flag words
   constexpr int VBASE = 4 * KTILE_BYTES;
