@@ -63,6 +63,16 @@ typedef struct ld_epilogue_t {
 int ld_gemm_bf16(const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
                  int64_t M, int64_t N, int64_t K, const ld_epilogue_t* epi, void* stream);
 
+/* The DiT's qkv Linear with the head split fused into its epilogue: ld_gemm_bf16 (bias) followed by ld_qkv_split mode 0,
+ * without the [M][3*heads*64] round trip through HBM.  Replaces attention.query_key_value + sat's _transpose_for_scores +
+ * query/key_layernorm of AdaLNMixin.attention_fn (landiff/diffusion/dit_video_concat.py:636-653).
+ * A [M = B*Ntok][K] bf16 (row stride lda), W [3*heads*64][K] (thirds q | k | v), bias [3*heads*64];
+ * Q, Kh [B][heads][Npad][64] = LayerNorm(64, eps) of the bf16 Linear output per head; Vt [B][heads][64][Npad] = V transposed.
+ * Rows [Ntok, Npad) of the three outputs are NOT written: zero-fill them once.  K % 64 == 0, Ntok % 8 == 0, Ntok >= 256. */
+int ld_gemm_qkv_heads(const void* A, int64_t lda, const void* W, const void* bias, int64_t M, int64_t K,
+                      void* Q, void* Kh, void* Vt, int64_t B, int64_t Ntok, int64_t heads, int64_t Npad,
+                      const void* q_w, const void* q_b, const void* k_w, const void* k_b, float eps, void* stream);
+
 /* Channels-last implicit-GEMM convolution, stride 1.
  * in_padded: bf16 [T+kT-1][H+kH-1][W+kW-1][Cin] with the zero spatial border and the causal time
  * halo already in place (the producer kernels write that layout); Wt: bf16 [Cout][kT][kH][kW][Cin];

@@ -53,6 +53,7 @@ SIGNATURES: dict[str, list] = {
     "ld_version": [],
     "ld_last_error": [],
     "ld_gemm_bf16": [P, I64, P, P, I64, I64, I64, I64, POINTER(Epilogue), P],
+    "ld_gemm_qkv_heads": [P, I64, P, P, I64, I64, P, P, P, I64, I64, I64, I64, P, P, P, P, c_float, P],
     "ld_conv_cl_bf16": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, POINTER(Epilogue), P],
     "ld_attn_fwd_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_float, P, P, P, P, P],
     "ld_attn_last_kernel": [],

@@ -61,6 +61,11 @@ struct GemmParams {
   const unsigned char* mx_w;
   unsigned char* mx_out;            // non-null: the output itself is MXFP8 (out = e4m3 bytes, ldo in bytes; scales here)
   long ld_mx_out;
+  // fused qkv head split (EPI_QKV): N = 3 * heads * 64 columns [q | k | v]; out is unused
+  bf16_t* q_out; bf16_t* k_out; bf16_t* vt_out;       // Q, K [B][heads][Npad][64], V^T [B][heads][64][Npad]
+  const bf16_t* qn_w; const bf16_t* qn_b; const bf16_t* kn_w; const bf16_t* kn_b;   // QK-LayerNorm(64) weights
+  int heads, Ntok, Npad;
+  float qk_eps;
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
@@ -165,7 +170,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, float (&v)[
 // than the instruction cache, so each tile paid tens of microseconds of instruction fetch.  The three epilogues of
 // the DiT layer are therefore compile-time specialisations (a few KB each, fully unrolled, operands of a row-block
 // requested before its accumulators are staged); everything else takes the compact generic path.
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE = 2, EPI_GENERIC = 3, EPI_GELU_MX = 4 };   // 4: bias + GELU, MXFP8 output
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE = 2, EPI_GENERIC = 3, EPI_GELU_MX = 4, EPI_QKV = 5 };   // 4: bias + GELU, MXFP8 output; 5: qkv head split
 
 // stage_block(ic) writes the 32 x 64 fp32 values of 32-row block ic of the wave tile into cw[32][CW_STRIDE] -- the only part
 // that depends on the MFMA shape the accumulators came from (gemm_epilogue: 32x32x16, gemm_epilogue16: 16x16x32).
@@ -337,8 +342,122 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&a
   gemm_epilogue_core<MI, EPI>(p, stage_block, cw, lane, row0, col0w);
 }
 
+// ------------------------------------------------------------------------------------------------
+// EPI_QKV: the DiT's qkv Linear with the head split fused into its epilogue (16x16x32 accumulators only).  Replaces the
+// Linear output + sat's _transpose_for_scores + query/key_layernorm of AdaLNMixin.attention_fn
+// (landiff/diffusion/dit_video_concat.py:636-653) -- i.e. ld_gemm_bf16 followed by ld_qkv_split mode 0 -- without the
+// [M][3*heads*64] round trip through HBM.  A wave's 64 output columns are exactly one head of q, k or v:
+//   q / k:  32-row blocks through the fp32 staging tile; the 8 lanes that hold a row's 64 columns do LayerNorm(64) on the
+//           bf16-rounded Linear output (same operation order as ld_qkv_split_kernel) and store the 128-byte row of
+//           Q / K [B][heads][Npad][64];
+//   v:      the accumulators go (bias added, rounded) straight into a TRANSPOSED bf16 tile [64 d][rows] in LDS -- a lane's four
+//           accumulator registers are four consecutive rows of one column, one ds_write_b64 -- and leave as 16-byte chunks
+//           of V^T [B][heads][64][Npad] rows, 8 tokens each (batch boundary and M are multiples of 8 rows).
+// Rows [Ntok, Npad) of Q / K / V^T are never written: the caller zero-fills those workspaces once.
+// LDS: QKV_REGION bytes per wave (wave-private: only the in-order execution of a wave's own DS instructions orders it).
+constexpr int QKV_REGION = 17408;      // >= 32 * CW_STRIDE * 4 (q/k staging) and 64 * (128 * 2 + 16) (v tile at 128 rows per wave)
+template <int MI>
+__device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&acc)[2 * MI][4], char* smem, int wave, int lane,
+                                               int row0, int col0w) {
+  if (col0w >= p.N) return;
+  const int head = col0w >> 6;
+  const int which = head / p.heads, h = head - which * p.heads;       // 0 = q, 1 = k, 2 = v
+  char* reg = smem + wave * QKV_REGION;
+  const int b0 = row0 / p.Ntok;
+  const int bnd = (b0 + 1) * p.Ntok;           // a wave tile (<= 128 rows, Ntok >= 256) crosses at most one batch boundary
+  if (which < 2) {
+    float* cw = (float*)reg;
+    const int sub = lane & 7, rsub = lane >> 3;
+    const bf16_t* nw = which ? p.kn_w : p.qn_w;
+    const bf16_t* nb = which ? p.kn_b : p.qn_b;
+    bf16_t* dst = which ? p.k_out : p.q_out;
+    float bias[8], wv[8], bv[8];
+    {
+      const u32x4_t bw = *(const u32x4_t*)(p.bias + col0w + sub * 8), ww = *(const u32x4_t*)(nw + sub * 8), nbw = *(const u32x4_t*)(nb + sub * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bias[2 * e] = bf_lo(bw[e]); bias[2 * e + 1] = bf_hi(bw[e]);
+        wv[2 * e] = bf_lo(ww[e]); wv[2 * e + 1] = bf_hi(ww[e]);
+        bv[2 * e] = bf_lo(nbw[e]); bv[2 * e + 1] = bf_hi(nbw[e]);
+      }
+    }
+    auto row_block = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+#pragma unroll
+      for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            cw[(di * 16 + (lane >> 4) * 4 + r) * CW_STRIDE + j * 16 + (lane & 15)] = acc[2 * i + di][j][r];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 8 + rsub;
+        const int gm = row0 + i * 32 + row;
+        const f32x4_t lo = *(const f32x4_t*)(cw + row * CW_STRIDE + sub * 8);
+        const f32x4_t hi = *(const f32x4_t*)(cw + row * CW_STRIDE + sub * 8 + 4);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = rbf(lo[e] + bias[e]); v[4 + e] = rbf(hi[e] + bias[4 + e]); }     // the bf16 Linear output
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float mean = s * (1.0f / 64.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; ss += d * d; }
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        const float rstd = rsqrtf(ss * (1.0f / 64.0f) + p.qk_eps);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf16x2((v[2 * e] - mean) * rstd * wv[2 * e] + bv[2 * e], (v[2 * e + 1] - mean) * rstd * wv[2 * e + 1] + bv[2 * e + 1]);
+        if (gm < p.M) {
+          const int b = gm >= bnd ? b0 + 1 : b0;
+          const int n = gm - b * p.Ntok;
+          *(u32x4_t*)(dst + (((long)b * p.heads + h) * p.Npad + n) * 64 + sub * 8) = o;
+        }
+      }
+    };
+    row_block(std::integral_constant<int, 0>{});
+    if constexpr (MI > 1) row_block(std::integral_constant<int, 1>{});
+    if constexpr (MI > 2) row_block(std::integral_constant<int, 2>{});
+    if constexpr (MI > 3) row_block(std::integral_constant<int, 3>{});
+  } else {
+    constexpr int ROWB = MI * 64 + 16;           // bytes per d row of the transposed tile (MI * 32 rows + pad, 16-byte aligned)
+    static_assert(64 * ROWB <= QKV_REGION, "v tile does not fit its LDS region");
+    float bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bj[j] = bf2f(p.bias[col0w + j * 16 + (lane & 15)]);
+#pragma unroll
+    for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x2_t w2;
+        w2[0] = pack_bf16x2(acc[i][j][0] + bj[j], acc[i][j][1] + bj[j]);
+        w2[1] = pack_bf16x2(acc[i][j][2] + bj[j], acc[i][j][3] + bj[j]);
+        *(u32x2_t*)(reg + (j * 16 + (lane & 15)) * ROWB + (i * 16 + (lane >> 4) * 4) * 2) = w2;
+      }
+    constexpr int CPR = MI * 4;                  // 16-byte chunks (8 rows) per d row
+#pragma unroll
+    for (int it = 0; it < CPR; ++it) {           // 64 * CPR chunks, 64 per trip
+      const int id = it * 64 + lane;
+      const int d = id / CPR, c = id - d * CPR;
+      const int gm = row0 + c * 8;
+      const u32x4_t val = *(const u32x4_t*)(reg + d * ROWB + c * 16);
+      if (gm < p.M) {
+        const int b = gm >= bnd ? b0 + 1 : b0;
+        const int n = gm - b * p.Ntok;
+        *(u32x4_t*)(p.vt_out + (((long)b * p.heads + h) * 64 + d) * p.Npad + n) = val;
+      }
+    }
+  }
+}
+
 // which specialisation a problem may use (the generic path handles everything)
 inline int pick_epilogue(const GemmParams& p) {
+  if (p.q_out) return EPI_QKV;
   if (p.mx_out) return EPI_GELU_MX;      // (the launcher checked: bias + GELU-tanh only, N % 32 == 0)
   const bool aligned = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) && !p.out_f32 && !p.mul;
   if (!aligned) return EPI_GENERIC;
@@ -575,7 +694,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   }
   __syncthreads();
 
-  if constexpr (M16) gemm_epilogue16<MI, EPI>(p, acc16, 0, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
+  if constexpr (EPI == EPI_QKV) {
+    static_assert(M16 || EPI != EPI_QKV, "the fused qkv split exists for the 16x16x32 accumulator layout only");
+    if constexpr (M16) qkv_epilogue16<MI>(p, acc16, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
+  } else if constexpr (M16) gemm_epilogue16<MI, EPI>(p, acc16, 0, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
   else gemm_epilogue<MI, NI, EPI>(p, acc, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
 }
 
@@ -1273,9 +1395,14 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int EPIB = NW * 32 * CW_STRIDE * 4;
   constexpr int SMEM = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
+  constexpr int SMEM_QKV = (SMEM > NW * QKV_REGION) ? SMEM : NW * QKV_REGION;
   const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   dim3 grid(nbm * nbn), block(NW * 64);
   const int epi = pick_epilogue(p);
+  if (epi == EPI_QKV) {
+    LD_REQUIRE(!conv, "ld_gemm_qkv_heads: not a convolution epilogue");
+    return launch_kernel<ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, false, EPI_QKV, true>>("ld_gemm_qkv_heads", grid, block, SMEM_QKV, stream, p);
+  }
   // 16x16x32 MFMAs by default (LD_GEMM_M16=0: the 32x32x16 form, kept for A/B measurements): +7...11 % on the DiT shapes
   static int m16 = -1;
   if (m16 < 0) { const char* e = getenv("LD_GEMM_M16"); m16 = e ? atoi(e) : 1; }
@@ -1397,6 +1524,7 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
   //  governor, and the 16x16x32 form costs less energy per FLOP)
   const bool w4r_default = false;
   auto big = [&](const GemmParams& q) {
+    if (q.q_out) return launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);      // the fused qkv split lives in the 16x16x32 kernels only
     if ((cfg == 11 || w4r_default) && pp_ok && !conv) return launch_w4r(q, stream);
     if (cfg == 8 && pp_ok) return launch_w4(q, conv, stream);
     return (cfg == 7 && pp_ok) ? launch_pp(q, conv, stream) : launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);
@@ -1561,6 +1689,29 @@ LD_API int ld_gemm_bf16(const void* A, int64_t lda, const void* W, void* out, in
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = lda; p.ldo = ldo;
   int rc = fill_epilogue(p, epi);
   if (rc) return rc;
+  return launch(p, false, (hipStream_t)stream);
+}
+
+LD_API int ld_gemm_qkv_heads(const void* A, int64_t lda, const void* W, const void* bias, int64_t M, int64_t K,
+                             void* Q, void* Kh, void* Vt, int64_t B, int64_t Ntok, int64_t heads, int64_t Npad,
+                             const void* q_w, const void* q_b, const void* k_w, const void* k_b, float eps, void* stream) {
+  LD_REQUIRE(A && W && bias && Q && Kh && Vt && q_w && q_b && k_w && k_b, "ld_gemm_qkv_heads: null pointer");
+  LD_REQUIRE(M == B * Ntok && B > 0 && heads > 0 && K > 0, "ld_gemm_qkv_heads: M=%ld must be B*Ntok=%ld", (long)M, (long)(B * Ntok));
+  LD_REQUIRE(K % BK == 0 && lda % 8 == 0, "ld_gemm_qkv_heads: K=%ld must be a multiple of %d, lda of 8", (long)K, BK);
+  LD_REQUIRE(Ntok % 8 == 0 && Ntok >= 256 && Npad % 8 == 0 && Npad >= Ntok, "ld_gemm_qkv_heads: Ntok=%ld (multiple of 8, >= 256), Npad=%ld", (long)Ntok, (long)Npad);
+  LD_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)Q & 15) == 0 &&
+             ((uintptr_t)Kh & 15) == 0 && ((uintptr_t)Vt & 15) == 0 && ((uintptr_t)q_w & 15) == 0 && ((uintptr_t)q_b & 15) == 0 &&
+             ((uintptr_t)k_w & 15) == 0 && ((uintptr_t)k_b & 15) == 0, "ld_gemm_qkv_heads: pointers must be 16-byte aligned");
+  LD_REQUIRE(M < (1LL << 31), "ld_gemm_qkv_heads: problem too large");
+  GemmParams p{};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.out = nullptr;
+  p.M = (int)M; p.N = (int)(3 * heads * 64); p.K = (int)K; p.lda = lda; p.ldo = 0;
+  int rc = fill_epilogue(p, nullptr);
+  if (rc) return rc;
+  p.bias = (const bf16_t*)bias;
+  p.q_out = (bf16_t*)Q; p.k_out = (bf16_t*)Kh; p.vt_out = (bf16_t*)Vt;
+  p.qn_w = (const bf16_t*)q_w; p.qn_b = (const bf16_t*)q_b; p.kn_w = (const bf16_t*)k_w; p.kn_b = (const bf16_t*)k_b;
+  p.heads = (int)heads; p.Ntok = (int)Ntok; p.Npad = (int)Npad; p.qk_eps = eps;
   return launch(p, false, (hipStream_t)stream);
 }
 

@@ -10,6 +10,8 @@ q/k live as [B][H][Npad][64], v transposed as [B][H][64][Npad]; all workspaces a
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -194,8 +196,13 @@ class ControlDiTRunner:
         ops.gemv(self.emb, lw["ada_w"], self.ada, bias=lw["ada_b"], in_act="silu")
         ops.layernorm(h_in, lw["ln1_w"], lw["ln1_b"], self.ln, c.block_ln_eps, shift_img=0, scale_img=d,
                       shift_txt=6 * d, scale_txt=7 * d, **mod)
-        self._linear(self.ln, lw, "qkv", self.qkv)
-        ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
+        if not self.fp8 and N % 8 == 0 and N >= 256 and os.environ.get("LD_DIT_FUSE_QKV", "1") != "0":
+            # qkv Linear + head split + QK-LayerNorm + V transpose in one launch (q / k / vt padding rows stay zero from allocation)
+            ops.gemm_qkv_heads(self.ln, lw["qkv_w"], lw["qkv_b"], self.q, self.k, self.vt, self.B, N, c.heads, self.Npad,
+                               lw["qln"], eps=c.qk_ln_eps)
+        else:
+            self._linear(self.ln, lw, "qkv", self.qkv)
+            ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
         self._attention()
         gate = dict(gate=self.ada, gate_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
         self._linear(self.attn.view(-1, d), lw, "dense", h_out, resid=h_in, gate_off_img=2 * d, gate_off_txt=8 * d, **gate)

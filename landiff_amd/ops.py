@@ -348,6 +348,18 @@ def vq_nearest(x, codebook, idx, dim):
                                     _stream()), "ld_vq_nearest")
 
 
+def gemm_qkv_heads(a, w, bias, q, k, vt, B, N, H, Npad, ln, eps=1e-6):
+    """The DiT qkv Linear with the head split in its epilogue: a [B*N, K] -> q, k [B,H,Npad,64] (QK-LayerNorm with
+    ln = (q_w, q_b, k_w, k_b)) and vt [B,H,64,Npad].  Rows [N, Npad) of q / k / vt are left as they are (keep them zero)."""
+    _bf16(a, "a"); _bf16(w, "w")
+    assert a.shape[0] == B * N and w.shape == (3 * H * 64, a.shape[1]) and a.stride(1) == 1 and w.is_contiguous()
+    assert q.shape == (B, H, Npad, 64) and k.shape == q.shape and vt.shape == (B, H, 64, Npad)
+    assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    check(_lib.load().ld_gemm_qkv_heads(_ptr(a), a.stride(0), _ptr(w), _ptr(bias), B * N, a.shape[1], _ptr(q), _ptr(k), _ptr(vt),
+                                        B, N, H, Npad, _ptr(ln[0]), _ptr(ln[1]), _ptr(ln[2]), _ptr(ln[3]), float(eps), _stream()),
+          "ld_gemm_qkv_heads")
+
+
 def qkv_split(qkv, q, k, vt, B, N, H, Npad, *, ln=None, rope=None, eps=1e-6):
     """ln = (q_w, q_b, k_w, k_b) for the DiT QK-LayerNorm, or rope = (cos, sin) [N,32] fp32 for TiTok."""
     mode = 0 if ln is not None else 1

@@ -71,3 +71,41 @@ def test_conv_cl(cuda, kT, kH, kW, T, H, W, Cin, Cout):
     out = ops.conv_cl(xp, wcl, T, H, W, bias=bias)
     ref_cl = ref[0].permute(1, 2, 3, 0).reshape(T * H * W, Cout)
     assert _rel(out, ref_cl) < 1e-2
+
+
+@pytest.mark.parametrize("B,N,H,K", [(2, 456, 3, 128), (1, 1000, 2, 192), (2, 4440, 5, 320)])
+def test_gemm_qkv_heads_fused_split(cuda, B, N, H, K):
+    """ld_gemm_qkv_heads (qkv Linear with QK-LayerNorm / head split / V transpose in its epilogue) against the two-launch
+    path it replaces (ld_gemm_bf16 + ld_qkv_split) and against a torch fp32 restatement of dit_video_concat.py:636-653.
+    Shapes: token counts that are not multiples of the 128-row wave tile (batch boundary inside a tile), a column count
+    that leaves dead waves in the last tile column, and one large enough for the 256x256 kernel + 128x128 tail launch."""
+    from landiff_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + N)
+    Npad = (N + 127) // 128 * 128
+    a = torch.randn(B * N, K, generator=g).to(cuda, torch.bfloat16)
+    w = (torch.randn(3 * H * 64, K, generator=g) * 0.08).to(cuda, torch.bfloat16)
+    bias = torch.randn(3 * H * 64, generator=g).to(cuda, torch.bfloat16)
+    ln = tuple((torch.randn(64, generator=g) * s + o).to(cuda, torch.bfloat16) for s, o in ((0.2, 1.0), (0.2, 0.0), (0.2, 1.0), (0.2, 0.0)))
+    eps = 1e-6
+    mk = lambda: (torch.zeros(B, H, Npad, 64, device=cuda, dtype=torch.bfloat16), torch.zeros(B, H, Npad, 64, device=cuda, dtype=torch.bfloat16),
+                  torch.zeros(B, H, 64, Npad, device=cuda, dtype=torch.bfloat16))
+    q1, k1, v1 = mk()
+    ops.gemm_qkv_heads(a, w, bias, q1, k1, v1, B, N, H, Npad, ln, eps=eps)
+    q2, k2, v2 = mk()
+    qkv = ops.gemm(a, w, bias=bias)
+    ops.qkv_split(qkv, q2, k2, v2, B, N, H, Npad, ln=ln, eps=eps)
+    # V is a pure data movement of the same bf16 values: exact.  q / k: the same fp32 LayerNorm on the same bf16 inputs
+    # (a fused multiply-add may contract differently in the two kernels: one bf16 ulp)
+    assert torch.equal(v1, v2)
+    for x1, x2 in ((q1, q2), (k1, k2)):
+        d = (x1.float() - x2.float()).abs()
+        assert (d <= 2.0 ** -7 * x2.float().abs() + 1e-6).all(), d.max().item()
+        assert (x1 != x2).float().mean().item() < 1e-3
+    assert float(q1[:, :, N:].abs().max()) == 0.0 and float(v1[:, :, :, N:].abs().max()) == 0.0     # padding rows untouched
+    # independent reference
+    y = (a.float() @ w.float().t() + bias.float()).to(torch.bfloat16).float().view(B, N, 3, H, 64)
+    lnf = lambda t, wv, bv: torch.nn.functional.layer_norm(t, (64,), wv.float(), bv.float(), eps)
+    qr = lnf(y[:, :, 0], ln[0], ln[1]).permute(0, 2, 1, 3)
+    kr = lnf(y[:, :, 1], ln[2], ln[3]).permute(0, 2, 1, 3)
+    vr = y[:, :, 2].permute(0, 2, 3, 1)
+    assert _rel(q1[:, :, :N], qr) < 1.5e-2 and _rel(k1[:, :, :N], kr) < 1.5e-2 and _rel(v1[:, :, :, :N], vr) < 1e-2
