@@ -103,6 +103,89 @@ __global__ __launch_bounds__(256, 1) void mfma_loop(const bf16x8* __restrict__ s
   if (total == 1234.5678f) sink[tid] = total;
 }
 
+// fp8 (e4m3, unit block scales) forms of the same 128x128-per-wave loop: VAR 5 = v_mfma_scale_f32_32x32x64_f8f6f4 (4x4 accumulators,
+// two fragment sets per 128 of K), VAR 6 = v_mfma_scale_f32_16x16x128_f8f6f4 (8x8 accumulators, one set)
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void mfma8_loop(const i32x8* __restrict__ src, float* sink, int iters) {
+  const int tid = threadIdx.x;
+  float total = 0.f;
+  if constexpr (VAR == 5) {
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    i32x8 a[2][4], b[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[p][i] = src[((p * 8 + i) * 256 + tid) % (1 << 15)]; b[p][i] = src[((p * 8 + 4 + i) * 256 + tid + 7777) % (1 << 15)]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[p][i], b[p][j], acc[i][j], 0, 0, 0, 127, 0, 127);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) total += acc[i][j][r];
+  } else {
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    i32x8 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = src[(i * 256 + tid) % (1 << 15)]; b[i] = src[((8 + i) * 256 + tid + 7777) % (1 << 15)]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[i][j], 0, 0, 0, 127, 0, 127);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) total += acc[i][j][r];
+  }
+  if (total == 1234.5678f) sink[tid] = total;
+}
+
+template <int VAR>
+void run8(const char* name, const i32x8* src, float* sink) {
+  const int iters = 2000, wgs = 256 * 4;
+  const double flop_launch = (double)wgs * 4 * iters * 2.0 * 128 * 128 * 128;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) mfma8_loop<VAR><<<wgs, 256>>>(src, sink, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0); mfma8_loop<VAR><<<wgs, 256>>>(src, sink, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms1; hipEventElapsedTime(&ms1, e0, e1);
+  const int n = (int)(1500.f / ms1) + 1;
+  hipEventRecord(e0);
+  for (int i = 0; i < n; ++i) mfma8_loop<VAR><<<wgs, 256>>>(src, sink, iters);
+  hipEventRecord(e1);
+  if (system("sleep 0.9; rocm-smi --showpower --showclocks 2>/dev/null | grep -E 'sclk|Package Power' | sed 's/^/      /'")) {}
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("%-58s %7.3f ms/launch  %6.0f TFLOP/s\n", name, ms / n, flop_launch * n / (ms * 1e-3) / 1e12);
+  fflush(stdout);
+}
+
 template <int VAR>
 void run(const char* name, const bf16x8* src, float* sink) {
   const int iters = 2000, wgs = 256 * 4;
@@ -146,5 +229,12 @@ int main(int argc, char** argv) {
   run<1>("16x16x32, register operands", src, sink);
   run<2>("32x32x16, operands from LDS (8 ds_read_b128 / 16 MFMA)", src, sink);
   run<3>("16x16x32, operands from LDS (16 ds_read_b128 / 64 MFMA)", src, sink);
+  // fp8: random e4m3 bytes (sign + 3 exponent + 3 mantissa bits toggling, no NaN / huge values), or zeros
+  std::vector<unsigned char> h8((size_t)(1 << 15) * 32);
+  for (auto& x : h8) x = zeros ? 0 : (unsigned char)(rand() & 0xb7);
+  i32x8* src8; hipMalloc(&src8, h8.size());
+  hipMemcpy(src8, h8.data(), h8.size(), hipMemcpyHostToDevice);
+  run8<5>("fp8 e4m3 32x32x64 (scale form, unit scales), registers", src8, sink);
+  run8<6>("fp8 e4m3 16x16x128 (scale form, unit scales), registers", src8, sink);
   return 0;
 }
