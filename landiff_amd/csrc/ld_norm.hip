@@ -95,11 +95,16 @@ __global__ __launch_bounds__(256) void ld_layernorm_kernel(LnParams p) {
       for (int e = 0; e < 4; ++e) {
         // modulate(): x * (1 + scale) + shift, every op in bf16 as in the reference
         const float s0 = rbf(1.0f + bf_lo(sc[e])), s1 = rbf(1.0f + bf_hi(sc[e]));
-        y[2 * e] = rbf(rbf(rbf(y[2 * e]) * s0) + bf_lo(sh[e]));
-        y[2 * e + 1] = rbf(rbf(rbf(y[2 * e + 1]) * s1) + bf_hi(sh[e]));
+        // (the last rounding, of the sum, is the one the bf16 pack / the out_f32 branch below performs)
+        y[2 * e] = rbf(rbf(y[2 * e]) * s0) + bf_lo(sh[e]);
+        y[2 * e + 1] = rbf(rbf(y[2 * e + 1]) * s1) + bf_hi(sh[e]);
       }
     }
     if (p.out_f32) {
+      if (shift) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = rbf(y[e]);
+      }
       float* o = (float*)p.out + (long)r * p.ldo + c * 8;
       *(f32x4_t*)o = (f32x4_t){y[0], y[1], y[2], y[3]};
       *(f32x4_t*)(o + 4) = (f32x4_t){y[4], y[5], y[6], y[7]};

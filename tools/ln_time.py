@@ -1,0 +1,17 @@
+"""Times the DiT LayerNorm + modulate launch (35552 x 1920 bf16 -> bf16)."""
+import sys, torch
+sys.path.insert(0, ".")
+from landiff_amd import ops
+M, d = 35552, 1920
+x = torch.randn(M, d, device="cuda").to(torch.bfloat16); out = torch.empty_like(x)
+w = torch.randn(d, device="cuda").to(torch.bfloat16); b = torch.randn(d, device="cuda").to(torch.bfloat16)
+ada = torch.randn(2, 12 * d, device="cuda").to(torch.bfloat16)
+fn = lambda: ops.layernorm(x, w, b, out, 1e-5, mod=ada, mod_bstride=12 * d, rows_per_batch=M // 2, text_len=226, shift_img=0, scale_img=d, shift_txt=6 * d, scale_txt=7 * d)
+for _ in range(5): fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50): fn()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 50
+print(f"layernorm+modulate: {ms * 1e3:.1f} us  {2 * M * d * 2 / ms / 1e9:.2f} TB/s  checksum {out.float().sum().item():.4f}")
