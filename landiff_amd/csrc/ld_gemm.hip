@@ -882,360 +882,9 @@ __global__ __launch_bounds__(512, 2) void ld_gemm_f8_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ping-pong main loop for the large DiT / TiTok GEMMs: 256x256 tile, 8 wave64 (2 along M x 4 along N, 128x64 per
-// wave = 4x2 MFMA 32x32x16 accumulators), two waves per SIMD that alternate roles every barrier interval:
-//
-//      wave group 0 (wr = 0):  B [load p] B [mfma p] B [load p+1] B [mfma p+1] ...
-//      wave group 1 (wr = 1):  B    B     [load p] B [mfma p]   B [load p+1] ...        (one barrier late)
-//
-// so that on every SIMD one wave owns the matrix pipe (8 MFMAs = one 16-deep k-step of its whole 128x64 tile) while
-// its partner issues the 6 ds_read_b128 of its next k-step and 2 LDS-DMA pieces of the prefetch stream.
-//   * K is consumed in 32-deep tiles (two phases each); LDS holds a ring of four 32 KB tiles (A 256x32 | W 256x32,
-//     64-byte rows, 16-byte chunk index XOR ((row >> 2) & 3) on the DMA source and on the read = conflict-free
-//     ds_read_b128).  The ring is fed in 16 KB units (unit u = A part (even) / W part (odd) of tile u/2), one unit per
-//     phase, unit u issued in phase u - 5.
-//   * RAW: the odd phase of tile t ends with a counted s_waitcnt vmcnt (3 units stay in flight) before its barrier; tile
-//     t + 1 is first read one barrier later (two for the late group).  WAR: unit u overwrites tile u/2 - 4, whose last
-//     ds_reads were retired (lgkmcnt(0) ahead of the MFMAs) by both groups at least one barrier before phase u - 5.
-//   * Raw s_barrier throughout: __syncthreads() would drain the LDS-DMA queue (vmcnt(0)) at every barrier.
-template <bool CONV, int EPI, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void ld_gemm_pp_kernel(GemmParams p) {
-  constexpr int BM = 256, BN = 256, KT = 32;
-  constexpr int A_BYTES = BM * KT * 2;              // 16 KB
-  constexpr int SLOT = (BM + BN) * KT * 2;          // 32 KB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-
-  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, nbm * nbn);
-  const int gm_sz = p.group_m;
-  const int per_group = gm_sz * nbn;
-  const int group = bid / per_group, in_group = bid - group * per_group;
-  const int first_m = group * gm_sz;
-  const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
-  const int m0 = p.m_begin + (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
-
-  // LDS-DMA sources: a 1 KB piece = 16 rows x 64 B; every wave brings 2 pieces of each 16 KB unit
-  const bf16_t* srcA[2];
-  const bf16_t* srcW[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (wave * 2 + i) * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((r >> 2) & 3);
-    int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
-    int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
-    if (CONV) {
-      const int hw = p.H * p.W_;
-      const int t = gm / hw, rem = gm - t * hw;
-      const int h = rem / p.W_, w = rem - h * p.W_;
-      srcA[i] = p.A + (((long)t * p.Hp + h) * p.Wp + w) * p.Cin + chunk * 8;
-    } else {
-      srcA[i] = p.A + (long)gm * p.lda + chunk * 8;
-    }
-    srcW[i] = p.W + (long)gn * p.K + chunk * 8;
-  }
-  const int nk = p.K / KT;            // K tiles (multiple of 4, checked by the launcher)
-  const int nunits = 2 * nk;
-  const int cpt = CONV ? p.Cin / KT : 1;
-  auto stage = [&](int slot, int u) {               // slot: compile-time at every call site
-    const int t = u >> 1;
-    char* base = smem + slot * SLOT + wave * 2048;
-    if ((u & 1) == 0) {
-      long koff;
-      if (CONV) {
-        const int tap = t / cpt, c0 = (t - tap * cpt) * KT;
-        const int khw = p.kH * p.kW;
-        const int dt = tap / khw, r2 = tap - dt * khw;
-        const int dh = r2 / p.kW, dw = r2 - dh * p.kW;
-        koff = (((long)dt * p.Hp + dh) * p.Wp + dw) * p.Cin + c0;
-      } else {
-        koff = (long)t * KT;
-      }
-      glds16(srcA[0] + koff, base);
-      glds16(srcA[1] + koff, base + 1024);
-    } else {
-      const long koff = (long)t * KT;
-      glds16(srcW[0] + koff, base + A_BYTES);
-      glds16(srcW[1] + koff, base + A_BYTES + 1024);
-    }
-  };
-
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment read offsets inside a slot for the two k-steps of a tile (+2048 B per further 32-row MFMA tile)
-  int rdA[2], rdB[2];
-  {
-    const int ra = wr * 128 + (lane & 31), rb = wc * 64 + (lane & 31);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int c = kk * 2 + (lane >> 5);
-      rdA[kk] = ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
-      rdB[kk] = A_BYTES + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
-    }
-  }
-
-  unsigned long long tL = 0, tB1 = 0, tM = 0, tB2 = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#define STAMP(x) do { if (DBG & 64) asm volatile("s_memtime %0" : "=s"(x)); } while (0)
-  auto phase = [&](auto slotc, auto kkc, int t) {
-    constexpr int S = decltype(slotc)::value, KK = decltype(kkc)::value;
-    // ---- load segment (partner wave is in its MFMA segment) ----
-    if (DBG & 64) {                   // previous phase's stamps are all retired here
-      unsigned long long s0n;
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s0n));
-      if (s3) { tL += s1 - s0; tB1 += s2 - s1; tM += s3 - s2; tB2 += s0n - s3; }
-      s0 = s0n;
-    }
-    bf16x8_t a[4], b[2];
-    if (DBG & 2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(a[i]));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(b[j]));
-    } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8_t*)(smem + rdA[KK] + S * SLOT + i * 2048);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8_t*)(smem + rdB[KK] + S * SLOT + j * 2048);
-    }
-    if (!(DBG & 1)) {
-      const int u = 2 * t + KK + 5;
-      if (u < nunits) stage(KK == 0 ? (S + 2) & 3 : (S + 3) & 3, u);
-    }
-    if (KK == 1) {
-      if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    STAMP(s1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    STAMP(s2);
-    // ---- MFMA segment ----
-    if (!(DBG & 16)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    if (!(DBG & 16)) __builtin_amdgcn_s_setprio(0);
-    STAMP(s3);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // ---- prologue: units 0..4 (tiles 0, 1 and the A part of tile 2), tile 0 complete, stagger the late group ----
-  stage(0, 0); stage(0, 1); stage(1, 2); stage(1, 3); stage(2, 4);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1 && !(DBG & 4)) __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int t = 0; t < nk; t += 4) {
-    phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t);
-    phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t);
-    phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t + 1);
-    phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, t + 1);
-    phase(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, t + 2);
-    phase(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, t + 2);
-    phase(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, t + 3);
-    phase(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, t + 3);
-  }
-  if (wr == 0 && !(DBG & 4)) __builtin_amdgcn_s_barrier();     // the early group waits for the late group's last MFMA segment
-  __syncthreads();
-  if (DBG & 64) {
-    asm volatile("s_waitcnt lgkmcnt(0)");
-    if (bid == 0 && lane == 0) {
-      unsigned long long* d = (unsigned long long*)p.out + wave * 4;
-      d[0] = tL; d[1] = tB1; d[2] = tM; d[3] = tB2;
-    }
-  }
-  if (DBG & 8) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
-    return;
-  }
-  gemm_epilogue<4, 2, EPI>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64);
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// One-wave-per-SIMD main loop: 256x256 tile, 4 wave64 as 2x2, each wave a 128x128 output = 4x4 MFMA 32x32x16
-// accumulators (256 registers; the kernel runs at one wave per SIMD, 512 registers per lane).  Compared with eight
-// 128x64 waves this reads a third less LDS per MFMA (8 ds_read_b128 per 16 MFMAs instead of 12) and needs no
-// load/compute role split: each wave software-pipelines itself -- the 8 fragment reads of k-step s+1 and this wave's
-// LDS-DMA pieces are issued between the 16 MFMAs of k-step s (order pinned with sched_barrier(0)), so the matrix pipe
-// sees back-to-back MFMAs on 16 independent accumulators.
-//   * K is consumed in 32-deep tiles; LDS holds a ring of four 32 KB tiles (A 256x32 | W 256x32, 64-byte rows, 16-byte
-//     chunk XOR ((row >> 2) & 3) on the DMA source and on the read).  The DMA is buffer_load ... lds with a loop-invariant
-//     per-lane voffset and the K offset in an SGPR: no VALU address arithmetic in the loop.
-//   * One barrier per K-tile, between its two k-steps.  Tile t's slot is last read during step (t,0) (fragments of
-//     (t,1)); after barrier B_t it is refilled with tile t+4.  RAW: before B_t every wave waits until only its pieces of
-//     tiles t+2, t+3 are outstanding (vmcnt(16)), so tile t+1 -- first read right after B_t -- is complete everywhere.
-template <bool CONV, int EPI>
-__global__ __launch_bounds__(256, 1) void ld_gemm_w4_kernel(GemmParams p) {
-  constexpr int BM = 256, BN = 256, KT = 32;
-  constexpr int A_BYTES = BM * KT * 2;              // 16 KB
-  constexpr int SLOT = (BM + BN) * KT * 2;          // 32 KB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-
-  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, nbm * nbn);
-  const int gm_sz = p.group_m;
-  const int per_group = gm_sz * nbn;
-  const int group = bid / per_group, in_group = bid - group * per_group;
-  const int first_m = group * gm_sz;
-  const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
-  const int m0 = p.m_begin + (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
-
-  // LDS-DMA: a 1 KB piece = 16 rows x 64 B; per K-tile every wave brings 4 pieces of A and 4 of W
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xffffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0xffffffff, 0x00020000);
-  uint32_t voA[4], voW[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave * 4 + i) * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((r >> 2) & 3);
-    int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
-    int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
-    if (CONV) {
-      const int hw = p.H * p.W_;
-      const int t = gm / hw, rem = gm - t * hw;
-      const int h = rem / p.W_, w = rem - h * p.W_;
-      voA[i] = (uint32_t)(((((long)t * p.Hp + h) * p.Wp + w) * p.Cin + chunk * 8) * 2);
-    } else {
-      voA[i] = (uint32_t)(((long)gm * p.lda + chunk * 8) * 2);
-    }
-    voW[i] = (uint32_t)(((long)gn * p.K + chunk * 8) * 2);
-  }
-  const int nk = p.K / KT;
-  const int cpt = CONV ? p.Cin / KT : 1;
-  auto koff_a = [&](int t) -> int {                 // byte offset of K-tile t in an A row (wave-uniform)
-    if (CONV) {
-      const int tap = t / cpt, c0 = (t - tap * cpt) * KT;
-      const int khw = p.kH * p.kW;
-      const int dt = tap / khw, r2 = tap - dt * khw;
-      const int dh = r2 / p.kW, dw = r2 - dh * p.kW;
-      return (int)(((((long)dt * p.Hp + dh) * p.Wp + dw) * p.Cin + c0) * 2);
-    }
-    return t * KT * 2;
-  };
-  // piece q of a tile's 8 (0-3: A, 4-7: W) for this wave
-  auto dma_piece = [&](int q, int slot, int soffA, int soffW) {
-    char* base = smem + slot * SLOT + wave * 4096;
-    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, voA[q], soffA, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + A_BYTES + (q - 4) * 1024), 16, voW[q - 4], soffW, 0, 0);
-  };
-
-  f32x16_t acc[2][4][2];       // [column half][row block][column block in the half]: the epilogue takes one half at a time
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
-
-  int rdA[2], rdB[2];          // fragment read offsets inside a slot for the two k-steps (+2048 B per further 32 rows)
-  {
-    const int ra = wr * 128 + (lane & 31), rb = wc * 128 + (lane & 31);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int c = kk * 2 + (lane >> 5);
-      rdA[kk] = ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
-      rdB[kk] = A_BYTES + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
-    }
-  }
-  bf16x8_t fa[2][4], fb[2][4];     // two fragment sets: the k-step being multiplied and the next one
-  auto FRAG = [&](auto bufc, int slot, int kk, int g) {       // g = 0..7: A row blocks 0-3, W column blocks 0-3
-    constexpr int B = decltype(bufc)::value;
-    if (g < 4) fa[B][g] = *(const bf16x8_t*)(smem + rdA[kk] + slot * SLOT + g * 2048);
-    else fb[B][g - 4] = *(const bf16x8_t*)(smem + rdB[kk] + slot * SLOT + (g - 4) * 2048);
-  };
-#define FENCE() __builtin_amdgcn_sched_barrier(0)
-  // one k-step: 16 MFMAs on fragment set B; behind them the 8 fragment reads of the next k-step (set 1-B, slot/kk given)
-  // and, if DMA, this wave's eight pieces of tile t+4.  No branches: a conditional around MFMAs makes hipcc keep two
-  // register assignments of the 256 accumulators and shuffle them at the join.
-  auto kstep = [&](auto bufc, int nslot, int nkk, auto dmac, int dslot, int soffA, int soffW) {
-    constexpr int B = decltype(bufc)::value;
-    constexpr bool DMA = decltype(dmac)::value;
-    using NB = std::integral_constant<int, 1 - B>;
-    // the 8 fragment reads go behind the first four MFMA pairs (two each): their LDS latency is covered by the remaining
-    // MFMAs of this k-step instead of stalling the first MFMA of the next one
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int i = g >> 1, j0 = (g & 1) * 2;
-      acc[j0 >> 1][i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[B][i], fb[B][j0], acc[j0 >> 1][i][0], 0, 0, 0);
-      if (g < 4) FRAG(NB{}, nslot, nkk, 2 * g);
-      acc[j0 >> 1][i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[B][i], fb[B][j0 + 1], acc[j0 >> 1][i][1], 0, 0, 0);
-      if (g < 4) FRAG(NB{}, nslot, nkk, 2 * g + 1);
-      if (DMA) dma_piece(g, dslot, soffA, soffW);
-      FENCE();
-    }
-  };
-  using T = std::true_type; using F = std::false_type;
-  using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
-
-  // ---- prologue: tiles 0..3 in flight, tile 0 complete, fragments of (0,0) ----
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int sa = koff_a(t), sw = t * KT * 2;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) dma_piece(q, t, sa, sw);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0070 | (24 & 15) | ((24 >> 4) << 14));   // vmcnt(24): tile 0 landed (nk >= 4, launcher)
-  __builtin_amdgcn_s_barrier();
-  FENCE();
-#pragma unroll
-  for (int g = 0; g < 8; ++g) FRAG(B0{}, 0, 0, g);
-
-  // ---- main loop over K-tiles; slot = t & 3 is a compile-time constant in the 4x unrolled body.  Every tile issues the
-  //      DMA of tile t+4 (index clamped past the end: tile nk-1 is re-fetched into a slot nobody reads) and prefetches the
-  //      fragments of (t+1,0) (stale LDS past the end, never multiplied): uniform vmcnt accounting, no branches.
-  auto tile = [&](auto slotc, int t) {
-    constexpr int S = decltype(slotc)::value;
-    const int td = t + 4 < nk ? t + 4 : nk - 1;
-    const int sa = koff_a(td), sw = td * KT * 2;
-    kstep(B0{}, S, 1, F{}, 0, 0, 0);                  // step (t,0): fragments of (t,1) from this tile's slot
-    __builtin_amdgcn_s_waitcnt(0x0070 | (16 & 15) | ((16 >> 4) << 14));   // vmcnt(16) lgkmcnt(0): tile t+1 complete
-    __builtin_amdgcn_s_barrier();                     // B_t: ... everywhere, and tile t's slot is free
-    FENCE();
-    kstep(B1{}, (S + 1) & 3, 0, T{}, S, sa, sw);      // step (t,1): fragments of (t+1,0); DMA of tile t+4 into slot S
-  };
-  for (int t = 0; t < nk; t += 4) {
-    tile(std::integral_constant<int, 0>{}, t);
-    tile(std::integral_constant<int, 1>{}, t + 1);
-    tile(std::integral_constant<int, 2>{}, t + 2);
-    tile(std::integral_constant<int, 3>{}, t + 3);
-  }
-#undef FENCE
-  __syncthreads();
-
-  gemm_epilogue<4, 2, EPI>(p, acc[0], smem, wave, lane, m0 + wr * 128, n0 + wc * 128);
-  gemm_epilogue<4, 2, EPI>(p, acc[1], smem, wave, lane, m0 + wr * 128, n0 + wc * 128 + 64);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Register-staged form of the one-wave-per-SIMD main loop (experiment for the LDS-feeding loss measured on
-// ld_gemm_w4_kernel, profiles/r01d_gemm_vs_vendor_library.txt): 256x256 tile, 4 waves x 128x128, K-tiles 64 deep on full
-// 128-byte lines.  Global memory -> VGPRs by buffer_load_dwordx4 (row offsets in SGPRs, out-of-range rows read as zero
+// One-wave-per-SIMD, register-staged main loop on v_mfma_f32_32x32x16_bf16 (the round-1 default, LD_GEMM_TILE=11; see
+// profiles/r01d_gemm_vs_vendor_library.txt for the measurements that shaped it): 256x256 tile, 4 waves x 128x128 = 4x4
+// accumulators of 16 registers (256 of the wave's 512 registers), K-tiles 64 deep on full 128-byte lines.  Global memory -> VGPRs by buffer_load_dwordx4 (row offsets in SGPRs, out-of-range rows read as zero
 // through the buffer descriptor's bounds check), two register sets = prefetch three K-tiles ahead; VGPRs -> LDS by
 // ds_write_b128 one tile ahead into a two-slot ring (2 x 64 KB, XOR-swizzled 16-byte chunks as in ld_gemm_kernel).
 //   tile t:  k-steps 0,1: 16 MFMA each + ds_write of K-tile t+1 (8 per k-step)     [its slot was last read in tile t-1]
@@ -1436,52 +1085,6 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
 #undef LD_GEMM_LAUNCH
 }
 
-int launch_pp(const GemmParams& p, bool conv, hipStream_t stream) {
-  constexpr int SMEM = 4 * (256 + 256) * 32 * 2;   // 128 KB ring (the epilogue staging reuses it)
-  const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
-  dim3 grid(nbm * nbn), block(512);
-  const int epi = pick_epilogue(p);
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("LD_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
-#define PP_DBG_CASE(D) case D: return launch_kernel<ld_gemm_pp_kernel<false, EPI_BIAS, D>>("ld_gemm_pp_dbg", grid, block, SMEM, stream, p);
-  if (dbg && !conv && epi == EPI_BIAS) switch (dbg) {
-    PP_DBG_CASE(1) PP_DBG_CASE(2) PP_DBG_CASE(3) PP_DBG_CASE(4) PP_DBG_CASE(8) PP_DBG_CASE(11) PP_DBG_CASE(16) PP_DBG_CASE(72) PP_DBG_CASE(73) PP_DBG_CASE(74) PP_DBG_CASE(75)
-    default: break;
-  }
-#undef PP_DBG_CASE
-#define LD_PP_LAUNCH(CONV_, EPI_) return launch_kernel<ld_gemm_pp_kernel<CONV_, EPI_>>("ld_gemm_pp", grid, block, SMEM, stream, p)
-  if (conv) {
-    if (epi == EPI_BIAS) LD_PP_LAUNCH(true, EPI_BIAS);
-    LD_PP_LAUNCH(true, EPI_GENERIC);
-  }
-  switch (epi) {
-    case EPI_BIAS: LD_PP_LAUNCH(false, EPI_BIAS);
-    case EPI_GELU: LD_PP_LAUNCH(false, EPI_GELU);
-    case EPI_GATE: LD_PP_LAUNCH(false, EPI_GATE);
-    default: LD_PP_LAUNCH(false, EPI_GENERIC);
-  }
-#undef LD_PP_LAUNCH
-}
-
-int launch_w4(const GemmParams& p, bool conv, hipStream_t stream) {
-  constexpr int SMEM = 4 * (256 + 256) * 32 * 2;   // 128 KB ring (the epilogue staging reuses it)
-  const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
-  dim3 grid(nbm * nbn), block(256);
-  const int epi = pick_epilogue(p);
-#define LD_W4_LAUNCH(CONV_, EPI_) return launch_kernel<ld_gemm_w4_kernel<CONV_, EPI_>>("ld_gemm_w4", grid, block, SMEM, stream, p)
-  if (conv) {
-    if (epi == EPI_BIAS) LD_W4_LAUNCH(true, EPI_BIAS);
-    LD_W4_LAUNCH(true, EPI_GENERIC);
-  }
-  switch (epi) {
-    case EPI_BIAS: LD_W4_LAUNCH(false, EPI_BIAS);
-    case EPI_GELU: LD_W4_LAUNCH(false, EPI_GELU);
-    case EPI_GATE: LD_W4_LAUNCH(false, EPI_GATE);
-    default: LD_W4_LAUNCH(false, EPI_GENERIC);
-  }
-#undef LD_W4_LAUNCH
-}
-
 int launch_w4r(const GemmParams& p, hipStream_t stream) {
   constexpr int SMEM = 2 * (256 + 256) * 64 * 2;   // two 64 KB K-tile slots (the epilogue staging reuses them)
   const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
@@ -1496,8 +1099,9 @@ int launch_w4r(const GemmParams& p, hipStream_t stream) {
 
 int launch(const GemmParams& p, bool conv, hipStream_t stream) {
   // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves, 3 = 256x256 / 8 waves (both 2-stage, barrier-drained, 16x16x32 MFMAs
-  // unless LD_GEMM_M16=0; 3 is the default for large problems when the knob is unset), 7 = 256x256 / 8 waves ping-pong main
-  // loop, 8 = 4 waves LDS-DMA pipelined, 11 = 4 waves register-staged (7 / 8 / 11: 32x32x16 MFMAs, round-1 experiments)
+  // unless LD_GEMM_M16=0; 3 is the default for large problems when the knob is unset), 11 = 4 waves x 128x128 register-staged
+  // on 32x32x16 MFMAs (the round-1 default, kept as the measured alternative; its two siblings -- an 8-wave load/compute
+  // ping-pong and a 4-wave LDS-DMA pipeline, within 2 % of it -- were removed in round 2)
   static int forced = -1, group_m = 8;
   if (forced < 0) {
     const char* e = getenv("LD_GEMM_TILE"); forced = e ? atoi(e) : 0;
@@ -1516,7 +1120,7 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     cfg = (tiles256 >= 512 && (conv ? (p.N >= 4096 || p.K >= 4096) : p.K >= 1024)) ? 3 : 1;
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
-  if (cfg != 3 && cfg != 7 && cfg != 8 && cfg != 11) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  if (cfg != 3 && cfg != 11) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
   // default for the large linear layers: the register-staged 4-wave loop (qkv / 4h / 4h->h GEMMs 3-6 % faster than the
   // 8-wave kernel); the gated-residual epilogue on a short K (DiT proj, K = 1920) hides its operand loads better with 8 waves
   // (round 1 default for the large linear layers: the register-staged 4-wave loop on 32x32x16 MFMAs, LD_GEMM_TILE=11; the
@@ -1526,8 +1130,7 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
   auto big = [&](const GemmParams& q) {
     if (q.q_out) return launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);      // the fused qkv split lives in the 16x16x32 kernels only
     if ((cfg == 11 || w4r_default) && pp_ok && !conv) return launch_w4r(q, stream);
-    if (cfg == 8 && pp_ok) return launch_w4(q, conv, stream);
-    return (cfg == 7 && pp_ok) ? launch_pp(q, conv, stream) : launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);
+    return launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);
   };
   // Wave quantisation: one 256x256 tile per CU at a time, so a grid of 4.3 "rounds" of 256 tiles costs 5.  When the last
   // round would be less than ~60 % full, the bottom rows are cut off and run as 128x128 tiles (two per CU, four times as

@@ -59,7 +59,7 @@ def _run(snippet, env):
     return float(line.split()[1])
 
 
-@pytest.mark.parametrize("env", [{"LD_GEMM_TILE": "7"}, {"LD_GEMM_TILE": "8"}, {"LD_GEMM_TILE": "11"}, {"LD_GEMM_TILE": "3", "LD_GEMM_MSPLIT": "0"},
+@pytest.mark.parametrize("env", [{"LD_GEMM_TILE": "11"}, {"LD_GEMM_TILE": "3", "LD_GEMM_MSPLIT": "0"},
                                  {"LD_GEMM_TILE": "1"}, {"LD_GEMM_TILE": "3", "LD_GEMM_M16": "0"}, {"LD_GEMM_TILE": "1", "LD_GEMM_M16": "0"}])
 def test_gemm_main_loop_variants(cuda, env):
     assert _run(GEMM_SNIPPET, env) < 1e-2
