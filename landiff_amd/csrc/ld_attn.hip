@@ -368,7 +368,7 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   dim3 grid((unsigned)(B * H * nqb)), block(256);
   static int var = -1;
   if (var < 0) {
-    // tuning knob: 0 = default (pipelined 16x16x32 kernel of ld_attn_p16.hip where it applies, else the plain kernel),
+    // tuning knob: 0 = default (pipelined 16x16x32 kernel of ld_attn_p16.hip for every unmasked problem of >= 6 key tiles, else the plain kernel),
     // 8 = the pipelined 32x32x16 kernel of ld_attn_pipe.hip (round-1 default), 9 = plain kernel everywhere,
     // 1 / 4 = plain kernel with row sums on the matrix pipe / lean-register 4-waves form
     const char* e = getenv("LD_ATTN_VARIANT");
@@ -377,8 +377,9 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   hipStream_t st = (hipStream_t)stream;
   const size_t s1 = 2 * STAGE_BYTES + 64;
   const int64_t nkt = (Nk + KT - 1) / KT;
-  if ((var == 0 || var == 8) && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {
-    return var == 0 ? ld_attn_p16_launch(p, st) : ld_attn_pipe2_launch(p, st);
+  if (var == 0 && !fid_k && nkt >= 6) return ld_attn_p16_launch(p, st);                  // any tile count
+  if (var == 8 && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {                              // (the round-1 kernel: tile counts 4 m + 2)
+    return ld_attn_pipe2_launch(p, st);
   } else if (var == 1) {
     g_attn_last_kernel = "ld_attn_kernel<1,true,false,true,2>";
     hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);

@@ -50,7 +50,7 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
   constexpr int QBW = NW * 32;                    // query rows per workgroup
   constexpr int NPW = 16 / NW;                    // LDS-DMA pieces per wave and tile (K: 8 pieces, V^T: 8 pieces)
   const int nqb = (p.Npad + QBW - 1) / QBW;
-  const int n = (p.Nk + KT - 1) / KT;             // >= 6 and (n - 2) % 4 == 0 (launcher)
+  const int n = (p.Nk + KT - 1) / KT;             // >= 6 (launcher)
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = bid / nqb, qblk = bid - bh * nqb;
@@ -322,10 +322,29 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
       iter(sA, sB, j + 2, S2{}, T{}, T{}, F{});
       iter(sB, sA, j + 3, S3{}, T{}, T{}, F{});
     }
-    // the two final iterations (j = n-2: masks tile n-1 if ragged, no K fragments to fetch; j = n-1: only finishes tile n-1)
-    if (n * KT > p.Nk) iter(sA, sB, j, S0{}, T{}, F{}, T{});
-    else iter(sA, sB, j, S0{}, T{}, F{}, F{});
-    iter(sB, sA, j + 1, S1{}, F{}, F{}, F{});
+    // the final n - j = 2 .. 5 iterations (j is a multiple of 4): full iterations while tile i+2 exists, then iteration n-2
+    // (masks tile n-1 if it is ragged, no K fragments to fetch) and iteration n-1 (only finishes tile n-1)
+    const bool ragged = n * KT > p.Nk;
+    const int rem = n - j;
+    if (rem == 2) {
+      if (ragged) iter(sA, sB, j, S0{}, T{}, F{}, T{}); else iter(sA, sB, j, S0{}, T{}, F{}, F{});
+      iter(sB, sA, j + 1, S1{}, F{}, F{}, F{});
+    } else if (rem == 3) {
+      iter(sA, sB, j, S0{}, T{}, T{}, F{});
+      if (ragged) iter(sB, sA, j + 1, S1{}, T{}, F{}, T{}); else iter(sB, sA, j + 1, S1{}, T{}, F{}, F{});
+      iter(sA, sB, j + 2, S2{}, F{}, F{}, F{});
+    } else if (rem == 4) {
+      iter(sA, sB, j, S0{}, T{}, T{}, F{});
+      iter(sB, sA, j + 1, S1{}, T{}, T{}, F{});
+      if (ragged) iter(sA, sB, j + 2, S2{}, T{}, F{}, T{}); else iter(sA, sB, j + 2, S2{}, T{}, F{}, F{});
+      iter(sB, sA, j + 3, S3{}, F{}, F{}, F{});
+    } else {
+      iter(sA, sB, j, S0{}, T{}, T{}, F{});
+      iter(sB, sA, j + 1, S1{}, T{}, T{}, F{});
+      iter(sA, sB, j + 2, S2{}, T{}, T{}, F{});
+      if (ragged) iter(sB, sA, j + 3, S3{}, T{}, F{}, T{}); else iter(sB, sA, j + 3, S3{}, T{}, F{}, F{});
+      iter(sA, sB, j + 4, S0{}, F{}, F{}, F{});
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       if constexpr (MSUM) {

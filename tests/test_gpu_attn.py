@@ -57,9 +57,13 @@ def test_attn_rescale_branch(cuda):
     assert _run(cuda, 1, 2, 700, spike=True) < 2e-2
 
 
-# key counts for which ld_attn_fwd_bf16 takes the software-pipelined kernel (ld_attn_pipe.hip): n = ceil(N/64) >= 6 and
-# (n - 2) % 4 == 0; 2175 has a ragged last tile, 1152 is an exact multiple of the query block
-@pytest.mark.parametrize("B,H,N", [(1, 2, 1122), (2, 1, 1400), (1, 1, 2175), (1, 1, 1152)])
+# key counts for which ld_attn_fwd_bf16 takes the software-pipelined kernel: n = ceil(N/64) >= 6 tiles (ld_attn_p16.hip, any n;
+# the round-1 kernel of ld_attn_pipe.hip, LD_ATTN_VARIANT=8, needs (n - 2) % 4 == 0); 2175 has a ragged last tile, 1152 is an
+# exact multiple of the query block
+@pytest.mark.parametrize("B,H,N", [(1, 2, 1122), (2, 1, 1400), (1, 1, 2175), (1, 1, 1152),
+                                   # every tile count modulo 4, ragged and exact last tiles (6 .. 13 tiles of 64 keys)
+                                   (1, 1, 384), (1, 1, 385), (1, 2, 448), (1, 1, 500), (1, 1, 512), (2, 1, 575), (1, 1, 640), (1, 1, 700),
+                                   (1, 1, 768), (1, 1, 830)])
 def test_attn_pipelined(cuda, B, H, N):
     assert _run(cuda, B, H, N, seed=N) < 2e-2
 
