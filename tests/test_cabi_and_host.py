@@ -189,3 +189,17 @@ def test_sat_checkpoint_layout_round_trip(tmp_path):
     assert set(out["tok"]) == {"decoder.mask_token", "mean"}
     assert set(out["ups"]) == {"upsample_model.conv_in.weight", "conv_out.weight"}
     assert set(out["vae"]) == {"decoder.conv_in.conv.weight"}
+
+
+def test_bench_refuses_a_gpu_count_that_is_not_the_world_size():
+    """bench.py --gpus N must equal WORLD_SIZE (one process per GPU under torch.distributed.run): a mismatch would report a
+    wrong n_gpus, so it stops before touching any device."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    env["WORLD_SIZE"] = "8"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=8" in (r.stderr + r.stdout)
