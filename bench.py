@@ -87,6 +87,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tiny", action="store_true", help="tiny random-init config (plumbing check, not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prompts-per-step", type=int, default=1,
+                    help="serving mode, NOT the BASELINE configuration (which is one prompt per GPU and step): P prompts per GPU "
+                         "and step through LanDiffPipeline.generate_many -- the AR decode of prompt i+1 runs on a second stream "
+                         "while prompt i is in the DiT loop; per-prompt results are identical to the one-prompt path")
     ap.add_argument("--stream-chunks", type=int, default=0,
                     help="BASELINE config 3 instead of the headline config: N-chunk streaming long video (prefix 7 latent "
                          "frames pinned per later chunk, LLM KV / latents / VAE conv caches reused in HBM)")
@@ -95,6 +99,8 @@ def main():
                          "linears -- mx (default): MXFP8 block scales, quantisation fused into LayerNorm / GELU epilogue; row: "
                          "per-row scales with quantise passes.  Reduced precision: not the headline metric, own workload name and dtype")
     args = ap.parse_args()
+    if args.prompts_per_step > 1 and (args.stream_chunks or args.fp8_gemm or args.tiny):
+        raise SystemExit("--prompts-per-step applies to the headline workload only")
     if args.fp8_gemm and not args.stream_chunks:
         raise SystemExit("--fp8-gemm belongs to the streaming long-video configuration (BASELINE configs[4]): add --stream-chunks N")
 
@@ -134,8 +140,15 @@ def main():
     # rank r works on prompt r (weak scaling: one prompt per GPU per step); same seed convention as a single-GPU run
     inp = synthetic_inputs(cfg, dev, n_text=64 if not args.tiny else 6, seed=42 + rank)
 
+    P = args.prompts_per_step
+    import dataclasses
+    inps = [dataclasses.replace(inp, seed=inp.seed + 1000 * i) for i in range(P)]
+
     def one_step():
-        frames = pipe.generate_stream(inp, stream, prefix_frames=prefix) if stream else pipe(inp)
+        if P > 1:
+            frames = torch.cat(pipe.generate_many(inps), dim=0)          # [P * 49, H, W, 3]
+        else:
+            frames = pipe.generate_stream(inp, stream, prefix_frames=prefix) if stream else pipe(inp)
         gathered = gather_frames(frames[None], world, force=use_dist)
         return gathered
 
@@ -182,9 +195,12 @@ def main():
                                     "(VPSDE DPM-Solver++(2M), DynamicCFG), bf16, random-init weights at true shapes")
                                    + (f"; streaming long video: {stream} chunks, {prefix} prefix latent frames pinned per later "
                                       f"chunk, {n_frames} frames" if stream else "")
-                                   + (f"; fp8 e4m3 MFMA ({args.fp8_gemm} scaling) for the DiT qkv/dense/4h/4h->h linears" if args.fp8_gemm else ""),
+                                   + (f"; fp8 e4m3 MFMA ({args.fp8_gemm} scaling) for the DiT qkv/dense/4h/4h->h linears" if args.fp8_gemm else "")
+                                   + (f"; SERVING MODE, not the BASELINE configuration: {P} prompts per GPU and step, AR decode of prompt "
+                                      f"i+1 overlapped with the DiT loop of prompt i (generate_many)" if P > 1 else ""),
                        "frames": n_frames, "height": 8 * d.latent_h, "width": 8 * d.latent_w,
                        "sampler_steps": cfg.sampler.num_steps, "llm_steps": (1244 if not stream else None) if not args.tiny else None,
+                       "prompts_per_step": P,
                        "parallelism": f"dp{world} over prompts, RCCL all_gather of uint8 frames only"},
             "stage_seconds_rank0": {k: round(v / args.steps, 3) for k, v in pipe.timings.items()},
             "roofline": {"kernel": "%s (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (kname, d.heads, d.seq_len),

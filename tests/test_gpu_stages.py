@@ -396,3 +396,21 @@ def test_sampling_filters_top_k_top_p(cuda, V, top_k, top_p):
     out = probs.cpu()
     assert torch.equal(out > 0, ref > 0), ((out > 0).sum().item(), (ref > 0).sum().item())
     assert (out - ref).abs().max().item() < 2e-6 and abs(out.sum().item() - 1) < 1e-5
+
+
+def test_generate_many_equals_per_prompt_runs(cuda, setup):
+    """LanDiffPipeline.generate_many (AR decode of prompt i+1 on a second stream / helper thread while prompt i is in the DiT
+    loop) returns, for every prompt, exactly the frames of a plain per-prompt call: the overlap must not leak into the RNG
+    streams, the token buffers or the conditioning state."""
+    import dataclasses
+    from landiff_amd.pipeline import LanDiffPipeline, synthetic_inputs
+    cfg, st = setup
+    pipe = LanDiffPipeline(cfg, st, cuda)
+    base = synthetic_inputs(cfg, cuda, n_text=6, seed=42)
+    inputs = [dataclasses.replace(base, seed=s) for s in (42, 43, 44)]
+    want = [pipe(inp).clone() for inp in inputs]
+    got = pipe.generate_many(inputs)
+    assert len(got) == 3
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not torch.equal(want[0], want[1])                    # different seeds do give different videos
