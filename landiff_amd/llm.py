@@ -218,12 +218,15 @@ class LLMRunner:
     def sample(self, text_emb: torch.Tensor, *, motion_score: float = 0.1, num_frames: int = 13, guidance_scale: float = 7.5,
                temperature: float = 1.0, seed: int | None = None, generator=None, use_graph: bool = False,
                teacher_fed=None, logits_log=None, top_k: int | None = None, top_p: float | None = None,
-               first_frame_tokens: torch.Tensor | None = None) -> torch.Tensor:
+               first_frame_tokens: torch.Tensor | None = None, on_segment=None, segment_tokens: int | None = None) -> torch.Tensor:
         """Returns the clamped visual token ids, int64 [n_visual] on the device (lm_model.py:509-516).
         top_k / top_p filter the unrestricted positions inside the sampling kernel (lm_model.py:441-447).
         first_frame_tokens (int64 [iframe_len], e.g. from TokenizerEncoder.encode_to_index): use_gt_first_frame of the
         reference (lm_model.py:332-352) -- the given I-frame tokens, END_OF_IFrame and the first START_OF_PFrame join the
-        prefilled prefix, sampling (and the RNG stream) starts at the first P token, the result begins with the given ids."""
+        prefilled prefix, sampling (and the RNG stream) starts at the first P token, the result begins with the given ids.
+        on_segment(s): called on the host right after the step that emits the last of every `segment_tokens` visual tokens
+        has been QUEUED (tokens [s * segment_tokens, (s + 1) * segment_tokens) of self.out_tokens are then final in stream
+        order) -- lets a streaming caller start on segment s while later segments are still being decoded."""
         c, dev = self.cfg, self.dev
         self.top_k, self.top_p = top_k, top_p
         guided = guidance_scale > 0 and guidance_scale != 1
@@ -254,9 +257,19 @@ class LLMRunner:
         if generator is None and seed:
             generator = torch.Generator(device=dev)
             generator.manual_seed(seed)                     # lm_model.py:398-402
+        emitted = 0
+        def note_position(pos):            # the token of position pos has just been queued
+            nonlocal emitted
+            if on_segment is None or pos in forced:
+                return
+            emitted += 1
+            if emitted % segment_tokens == 0:
+                on_segment(emitted // segment_tokens - 1)
+        assert on_segment is None or (segment_tokens and first_frame_tokens is None)
         self._prefill(feats)
         self.pos.fill_(S_last)
         self._sample_and_advance(guided, guidance_scale, temperature, generator)
+        note_position(S_last + 1)
         if logits_log is not None:
             logits_log.append(self.cfg_logits.clone())
         steps = full_len - (S_last + 1) - 1
@@ -273,6 +286,7 @@ class LLMRunner:
             else:
                 self._decode_forward()
                 self._sample_and_advance(guided, guidance_scale, temperature, generator)
+            note_position(S_last + 2 + it)
             if logits_log is not None:
                 logits_log.append(self.cfg_logits.clone())
         self.host_enqueue_s = time.perf_counter() - t_enq      # host time to enqueue the loop (< wall time when the GPU is the bound)

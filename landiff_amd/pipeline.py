@@ -52,7 +52,7 @@ class LanDiffPipeline:
         self.timings = {}
 
     def _t(self, name, t0):
-        torch.cuda.synchronize(self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()      # (the stage's own stream: an overlapped AR decode keeps running)
         self.timings[name] = self.timings.get(name, 0.0) + time.perf_counter() - t0
 
     @torch.no_grad()
@@ -157,7 +157,7 @@ class LanDiffPipeline:
 
     @torch.no_grad()
     def generate_stream(self, inp: PromptInputs, n_chunks: int, prefix_frames: int = 7, want_float: bool = False,
-                        tokens: torch.Tensor | None = None, noises=None, randn_like=torch.randn_like):
+                        tokens: torch.Tensor | None = None, noises=None, randn_like=torch.randn_like, overlap_decode: bool = True):
         """Chunked long-video generation out of the reference's streaming primitives -- the reference ships the pieces
         (yaml :213,231 "fixed_frames: 7 # 49 frames, 13 latent, prefix_length=7"), not the loop:
           * ONE multi-segment AR decode (Semantic1DLM.sample with num_frames = n_seg * segment_length, lm_model.py:278-291,
@@ -171,22 +171,68 @@ class LanDiffPipeline:
         Chunk c is seeded with inp.seed + c.  Returns uint8 frames [4T-3 + (n_chunks-1)*4*new, H, W, 3] (+ fp32 video)."""
         d, lc = self.cfg.dit, self.cfg.llm
         T, new, n_seg = self.stream_plan(n_chunks, prefix_frames)
-        t0 = time.perf_counter()
-        if tokens is None:
-            torch.manual_seed(inp.seed); torch.cuda.manual_seed(inp.seed)
-            tokens = self.llm.sample(inp.llm_text_emb, motion_score=inp.motion_score, num_frames=n_seg * lc.segment_length,
-                                     guidance_scale=inp.cfg, temperature=1.0, seed=inp.seed)
-        self._t("llm", t0)
-        t0 = time.perf_counter()
         per_seg = self.cfg.tok.num_latent_tokens
-        tokens = tokens.to(self.dev).reshape(n_seg, per_seg)
-        sem_all = torch.cat([self.detok.semantic_condition(tokens[s]) for s in range(n_seg)], dim=0)   # [n_seg*T, C, H, W]
-        self._t("detokenize", t0)
+        t0 = time.perf_counter()
+        seg_tokens = None          # segment s -> its token ids, int64 [per_seg] on the device
+        decode_thread = None
+        if tokens is None and overlap_decode and inp.seed:
+            # The multi-segment AR decode runs on a second, high-priority stream issued by a helper thread; chunk c only needs
+            # the segments its 13 latent frames fall into, so the DiT loop of the first chunk starts as soon as segment 0 is
+            # decoded and the later segments are decoded underneath it (980 W of HBM-bound launches next to the power-capped
+            # MFMA kernels: see generate_many).  The decode draws from its own generator (seed given), so the tokens equal
+            # those of the serial path.
+            import threading
+            side = torch.cuda.Stream(device=self.dev, priority=-1)
+            queued = [threading.Event() for _ in range(n_seg)]
+            done = [torch.cuda.Event() for _ in range(n_seg)]
+            def on_segment(sidx):
+                done[sidx].record(side)
+                queued[sidx].set()
+            decode_state = {"t_start": time.perf_counter()}
+            def run_decode():
+                try:
+                    torch.cuda.set_device(self.dev)
+                    with torch.cuda.stream(side):
+                        self.llm.sample(inp.llm_text_emb, motion_score=inp.motion_score, num_frames=n_seg * lc.segment_length,
+                                        guidance_scale=inp.cfg, temperature=1.0, seed=inp.seed, on_segment=on_segment, segment_tokens=per_seg)
+                        side.synchronize()
+                    decode_state["seconds"] = time.perf_counter() - decode_state["t_start"]
+                except BaseException as e:              # never leave the consumer waiting on a segment that will not come
+                    decode_state["error"] = e
+                    for ev in queued:
+                        ev.set()
+            decode_thread = threading.Thread(target=run_decode)
+            decode_thread.start()
+            def seg_tokens(sidx):
+                queued[sidx].wait()
+                if "error" in decode_state:
+                    raise decode_state["error"]
+                torch.cuda.current_stream(self.dev).wait_event(done[sidx])
+                return self.llm.out_tokens[sidx * per_seg:(sidx + 1) * per_seg].clamp(0, lc.visual_vocab - 1)
+        else:
+            if tokens is None:
+                torch.manual_seed(inp.seed); torch.cuda.manual_seed(inp.seed)
+                tokens = self.llm.sample(inp.llm_text_emb, motion_score=inp.motion_score, num_frames=n_seg * lc.segment_length,
+                                         guidance_scale=inp.cfg, temperature=1.0, seed=inp.seed)
+            self._t("llm", t0)
+            tokens = tokens.to(self.dev).reshape(n_seg, per_seg)
+            seg_tokens = lambda sidx: tokens[sidx]
+        sem_seg = {}               # segment -> semantic features [T, C, H, W], computed when a chunk first needs them
+        def sem_window(f0, f1):    # latent frames [f0, f1) of the concatenated per-segment features
+            parts = []
+            for sidx in range(f0 // T, (f1 - 1) // T + 1):
+                if sidx not in sem_seg:
+                    t1 = time.perf_counter()
+                    sem_seg[sidx] = self.detok.semantic_condition(seg_tokens(sidx))
+                    self._t("detokenize", t1)
+                lo, hi = max(f0, sidx * T) - sidx * T, min(f1, (sidx + 1) * T) - sidx * T
+                parts.append(sem_seg[sidx][lo:hi])
+            return torch.cat(parts, dim=0).contiguous()
         outs, vids, prev = [], [], None
         for c in range(n_chunks):
             t0 = time.perf_counter()
             torch.manual_seed(inp.seed + c); torch.cuda.manual_seed(inp.seed + c)
-            self.dit.set_condition(inp.dit_context, sem_all[c * new: c * new + T].contiguous())
+            self.dit.set_condition(inp.dit_context, sem_window(c * new, c * new + T))
             noise = noises[c].to(self.dev) if noises is not None else torch.randn(
                 1, T, d.in_channels, d.latent_h, d.latent_w, device=self.dev, dtype=torch.float32)
             if c == 0:
@@ -204,6 +250,11 @@ class LanDiffPipeline:
                 outs.append(r[0]); vids.append(r[1])
             else:
                 outs.append(r)
+        if decode_thread is not None:
+            decode_thread.join()
+            if "error" in decode_state:
+                raise decode_state["error"]
+            self.timings["llm_overlapped"] = self.timings.get("llm_overlapped", 0.0) + decode_state["seconds"]   # wall time of the decode thread
         frames = torch.cat(outs, dim=0)
         return (frames, torch.cat(vids, dim=1)) if want_float else frames
 

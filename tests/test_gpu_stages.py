@@ -414,3 +414,16 @@ def test_generate_many_equals_per_prompt_runs(cuda, setup):
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     assert not torch.equal(want[0], want[1])                    # different seeds do give different videos
+
+
+def test_streaming_overlapped_decode_equals_serial(cuda, setup):
+    """generate_stream with the multi-segment AR decode running on a second stream under the chunk loop (the default) returns
+    exactly the frames of the serial order (decode everything, then the chunks)."""
+    from landiff_amd.pipeline import LanDiffPipeline, synthetic_inputs
+    cfg, st = setup
+    pipe = LanDiffPipeline(cfg, st, cuda, max_llm_frames=3 * cfg.llm.segment_length)
+    inp = synthetic_inputs(cfg, cuda, n_text=6, seed=42)
+    serial = pipe.generate_stream(inp, 3, prefix_frames=1, overlap_decode=False).clone()
+    over = pipe.generate_stream(inp, 3, prefix_frames=1)
+    assert "llm_overlapped" in pipe.timings
+    assert torch.equal(serial, over)
