@@ -146,6 +146,16 @@ class LanDiffPipeline:
                 out.append(self.vae.decode(z.to(torch.bfloat16).float(), want_float=want_float))
         return out
 
+    @torch.no_grad()
+    def generate_batch(self, inputs: list, rank: int = 0, world: int = 1) -> list:
+        """A batch of prompts data-parallel over the GPUs of a node (BASELINE configs[3]; the reference's only hook is
+        LOCAL_RANK -> set_device, infer_video.py:109-110): this rank runs prompts rank, rank + world, ... through
+        generate_many (per-prompt seeds, so a prompt's frames do not depend on the number of GPUs) and one RCCL all_gather
+        returns every prompt's uint8 frames, in prompt order, on every rank."""
+        mine = shard_prompts(len(inputs), rank, world)
+        local = self.generate_many([inputs[i] for i in mine])
+        return gather_prompt_frames(local, len(inputs), rank, world)
+
     # ---- streaming long video (SURVEY 8f rank 2; BASELINE config 3) --------------------------------
     def stream_plan(self, n_chunks: int, prefix_frames: int):
         """(latent frames per chunk, new latent frames per later chunk, LLM segments needed)."""
@@ -285,4 +295,36 @@ def gather_frames(frames: torch.Tensor, world: int, force: bool = False):
         return [frames]
     out = [torch.empty_like(frames) for _ in range(world)]
     dist.all_gather(out, frames.contiguous())
+    return out
+
+
+def gather_prompt_frames(local_frames: list, n_prompts: int, rank: int, world: int, force: bool = False) -> list:
+    """The final gather of a prompt batch (BASELINE configs[3]): rank r holds the uint8 frames [T, H, W, 3] of prompts
+    shard_prompts(n_prompts, r, world), in that order; every rank gets back the frames of ALL prompts in prompt order.
+    Shards may be uneven (n_prompts not a multiple of world): the short ranks pad with one zero video, which is dropped again.
+    One all_gather per batch -- the only collective of the data-parallel path."""
+    mine = shard_prompts(n_prompts, rank, world)
+    assert len(local_frames) == len(mine), (len(local_frames), len(mine))
+    per_rank = -(-n_prompts // world)
+    if not local_frames and per_rank == 0:
+        return []
+    ref = local_frames[0] if local_frames else None
+    import torch.distributed as dist
+    live = dist.is_initialized() and world > 1
+    if ref is not None:
+        dev = ref.device
+    else:                  # a rank with no prompt at all (world > n_prompts) learns the frame shape from rank 0
+        dev = torch.device("cuda", torch.cuda.current_device()) if live and dist.get_backend() == "nccl" else torch.device("cpu")
+    shape = torch.tensor(ref.shape if ref is not None else (0, 0, 0, 0), dtype=torch.int64, device=dev)
+    if live:
+        dist.broadcast(shape, src=0)
+    T, H, W, C = (int(v) for v in shape.tolist())
+    stack = torch.zeros(per_rank, T, H, W, C, dtype=torch.uint8, device=dev)
+    for i, f in enumerate(local_frames):
+        stack[i] = f
+    gathered = gather_frames(stack, world, force=force)
+    out = [None] * n_prompts
+    for r, g in enumerate(gathered):
+        for i, pid in enumerate(shard_prompts(n_prompts, r if len(gathered) > 1 else rank, world)):
+            out[pid] = g[i]
     return out

@@ -28,6 +28,38 @@ def _worker(rank, world, port, q):
     q.put((rank, ok, mine))
 
 
+def _worker_uneven(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from landiff_amd.pipeline import gather_prompt_frames, shard_prompts
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_prompts = 3                                                  # rank 0: prompts 0, 2; rank 1: prompt 1
+    mine = shard_prompts(n_prompts, rank, world)
+    local = [torch.full((3, 4, 6, 3), 10 * p + 1, dtype=torch.uint8) for p in mine]
+    out = gather_prompt_frames(local, n_prompts, rank, world)
+    ok = len(out) == n_prompts and all(bool((out[p] == 10 * p + 1).all()) and tuple(out[p].shape) == (3, 4, 6, 3) for p in range(n_prompts))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok, mine))
+
+
+def test_two_rank_uneven_prompt_batch():
+    """gather_prompt_frames: 3 prompts over 2 ranks -- every rank ends up with all videos in prompt order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker_uneven, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res)
+    assert sorted(sum((m for _, _, m in res), [])) == [0, 1, 2]
+
+
 def test_two_rank_gather():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
