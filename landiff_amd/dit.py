@@ -116,6 +116,10 @@ class ControlDiTRunner:
             self.s8d = torch.empty(d // 128, M, 4, device=device, dtype=torch.uint8)       # scales, K-tile-major
             self.s8m = torch.empty(4 * d // 128, M, 4, device=device, dtype=torch.uint8)   # ... and 4d (codes in self.a8)
         self.sem = None                         # [T, C, H, W] bf16, set per video
+        # qkv Linear + QK-LayerNorm + head split + V transpose in one launch (ld_gemm_qkv_heads) where its shape rules hold;
+        # LD_DIT_FUSE_QKV=0 keeps the two-launch form (A/B timing)
+        self.fuse_qkv = (not self.fp8 and self.N % 8 == 0 and self.N >= 256 and c.head_dim == 64
+                         and os.environ.get("LD_DIT_FUSE_QKV", "1") != "0")
         self.attn_events = None                 # bench.py: list of (start, end) HIP events around every attention launch
 
     # ---- per-video setup -------------------------------------------------------------------
@@ -196,7 +200,7 @@ class ControlDiTRunner:
         ops.gemv(self.emb, lw["ada_w"], self.ada, bias=lw["ada_b"], in_act="silu")
         ops.layernorm(h_in, lw["ln1_w"], lw["ln1_b"], self.ln, c.block_ln_eps, shift_img=0, scale_img=d,
                       shift_txt=6 * d, scale_txt=7 * d, **mod)
-        if not self.fp8 and N % 8 == 0 and N >= 256 and os.environ.get("LD_DIT_FUSE_QKV", "1") != "0":
+        if self.fuse_qkv:
             # qkv Linear + head split + QK-LayerNorm + V transpose in one launch (q / k / vt padding rows stay zero from allocation)
             ops.gemm_qkv_heads(self.ln, lw["qkv_w"], lw["qkv_b"], self.q, self.k, self.vt, self.B, N, c.heads, self.Npad,
                                lw["qln"], eps=c.qk_ln_eps)
