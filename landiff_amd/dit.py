@@ -60,6 +60,11 @@ class _Branch:
                 for name in ("qkv", "dense", "h4", "h1"):
                     lw[name + "_w8"], lw[name + "_s"] = quant(lw.pop(name + "_w"))
             self.layers.append(lw)
+        # all layers' adaLN modulation Linear stacked: the time embedding is the same for every layer of a step, so ONE
+        # weight-streaming GEMV per branch and step produces all 12 x hidden modulation vectors (the per-layer tensors are
+        # dropped: views into the stack would only keep two copies alive)
+        self.ada_w_all = torch.cat([lw.pop("ada_w") for lw in self.layers], 0).contiguous()      # [L * 12 d, time_embed_dim]
+        self.ada_b_all = torch.cat([lw.pop("ada_b") for lw in self.layers], 0).contiguous()
         if not control:
             f = "mixins.final_layer."
             self.fln_w, self.fln_b = g("transformer.final_layernorm.weight"), g("transformer.final_layernorm.bias")
@@ -102,7 +107,9 @@ class ControlDiTRunner:
         self.temb = e(B, d)
         self.emb_h = e(B, c.time_embed_dim)
         self.emb = e(B, c.time_embed_dim)
-        self.ada = e(B, 12 * d)
+        # modulation vectors of every layer of a branch for the current step: [B][L][12 d]
+        self.ada_main = e(B, self.main.L * 12 * d)
+        self.ada_ctrl = e(B, self.ctrl.L * 12 * d)
         self.fada = e(B, 2 * d)
         self.lin = e(B, c.n_img, c.patch * c.patch * c.out_channels)
         self.tvec = e(B, dt=torch.float32)
@@ -140,6 +147,20 @@ class ControlDiTRunner:
         ops.timestep_embedding(self.tvec, self.temb)
         ops.gemv(self.temb, br.te0_w, self.emb_h, bias=br.te0_b)
         ops.gemv(self.emb_h, br.te2_w, self.emb, bias=br.te2_b, in_act="silu")
+        self._modulations(br)
+
+    def _modulations(self, br: _Branch):
+        """adaLN_modulations[l] = Linear(SiLU(emb)) for every layer l of the branch (dit_video_concat.py:540-566), one launch:
+        self.emb [B, time_embed_dim] -> [B, L * 12 hidden]."""
+        ops.gemv(self.emb, br.ada_w_all, self._ada_all(br), bias=br.ada_b_all, in_act="silu")
+
+    def _ada_all(self, br: _Branch):
+        return self.ada_ctrl if br is self.ctrl else self.ada_main
+
+    def _ada(self, br: _Branch, i: int):
+        """(view of layer i's 12 x hidden modulation vectors [B, 12 d], batch stride in elements)"""
+        a, d12 = self._ada_all(br), 12 * self.cfg.hidden
+        return a[:, i * d12:(i + 1) * d12], a.stride(0)
 
     def _embed(self, br: _Branch, x: torch.Tensor, h: torch.Tensor, txt: torch.Tensor, sem):
         c = self.cfg
@@ -173,9 +194,9 @@ class ControlDiTRunner:
         """_layer with MXFP8 operands on the four large linears (fp8_gemm="mx")."""
         c, lw = self.cfg, br.layers[i]
         d, N = c.hidden, self.N
-        mod = dict(mod=self.ada, mod_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
-        gate = dict(gate=self.ada, gate_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
-        ops.gemv(self.emb, lw["ada_w"], self.ada, bias=lw["ada_b"], in_act="silu")
+        ada, ada_bs = self._ada(br, i)
+        mod = dict(mod=ada, mod_bstride=ada_bs, rows_per_batch=N, text_len=c.text_len)
+        gate = dict(gate=ada, gate_bstride=ada_bs, rows_per_batch=N, text_len=c.text_len)
         ops.layernorm_mxfp8(h_in, lw["ln1_w"], lw["ln1_b"], self.a8d, self.s8d, c.block_ln_eps, shift_img=0, scale_img=d,
                             shift_txt=6 * d, scale_txt=7 * d, **mod)
         ops.gemm_mxfp8(self.a8d, self.s8d, lw["qkv_w8"], lw["qkv_s"], out=self.qkv, bias=lw["qkv_b"])
@@ -196,8 +217,8 @@ class ControlDiTRunner:
             return self._layer_mx(br, i, h_in, h_out, control_add)
         c, lw = self.cfg, br.layers[i]
         d, N = c.hidden, self.N
-        mod = dict(mod=self.ada, mod_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
-        ops.gemv(self.emb, lw["ada_w"], self.ada, bias=lw["ada_b"], in_act="silu")
+        ada, ada_bs = self._ada(br, i)
+        mod = dict(mod=ada, mod_bstride=ada_bs, rows_per_batch=N, text_len=c.text_len)
         ops.layernorm(h_in, lw["ln1_w"], lw["ln1_b"], self.ln, c.block_ln_eps, shift_img=0, scale_img=d,
                       shift_txt=6 * d, scale_txt=7 * d, **mod)
         if self.fuse_qkv:
@@ -208,7 +229,7 @@ class ControlDiTRunner:
             self._linear(self.ln, lw, "qkv", self.qkv)
             ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
         self._attention()
-        gate = dict(gate=self.ada, gate_bstride=12 * d, rows_per_batch=N, text_len=c.text_len)
+        gate = dict(gate=ada, gate_bstride=ada_bs, rows_per_batch=N, text_len=c.text_len)
         self._linear(self.attn.view(-1, d), lw, "dense", h_out, resid=h_in, gate_off_img=2 * d, gate_off_txt=8 * d, **gate)
         ops.layernorm(h_out, lw["ln2_w"], lw["ln2_b"], self.ln, c.block_ln_eps, shift_img=3 * d, scale_img=4 * d,
                       shift_txt=9 * d, scale_txt=10 * d, **mod)

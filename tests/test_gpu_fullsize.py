@@ -139,6 +139,7 @@ def test_dit_layer_full_shape_vs_oracle(cuda):
         ref = DiTOracle(sd_main, d1, False, torch.float32).layer(0, h.float(), emb.float())
     run = ControlDiTRunner(sd_main, sd_ctrl, d1, cuda)
     run.emb.copy_(emb.to(cuda))
+    run._modulations(run.main)
     h_dev = h.to(cuda).reshape(-1, d1.hidden).contiguous()
     out = torch.empty_like(h_dev)
     run._layer(run.main, 0, h_dev, out)
