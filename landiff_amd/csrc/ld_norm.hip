@@ -10,6 +10,7 @@
 // All of these are pure streaming passes: 16-byte coalesced loads, one wave64 per row (no LDS, no barriers)
 // for the LayerNorms, fp32 statistics, bf16 outputs rounded at the same points the reference's bf16 ops round.
 #include "ld_common.h"
+#include <stdlib.h>
 #include "../../include/landiff_hip.h"
 
 namespace {
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void ld_layernorm_kernel(LnParams p) {
   if (r >= p.rows) return;
   const int nchunk = p.D >> 3;
   float v[NC][8];
-  float s = 0.f;
+  float s = 0.f, s_odd = 0.f;       // even / odd elements summed apart: the order of ld_layernorm_mod_kernel's packed sums
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
@@ -52,19 +53,22 @@ __global__ __launch_bounds__(256) void ld_layernorm_kernel(LnParams p) {
         for (int e = 0; e < 4; ++e) { v[i][2 * e] = bf_lo(a[e]); v[i][2 * e + 1] = bf_hi(a[e]); }
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[i][e];
+      for (int e = 0; e < 4; ++e) { s += v[i][2 * e]; s_odd += v[i][2 * e + 1]; }
     }
   }
-  const float mean = wave_sum(s) / (float)p.D;
-  float ss = 0.f;
+  const float mean = wave_sum(s + s_odd) / (float)p.D;
+  float ss = 0.f, ss_odd = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     if (lane + 64 * i < nchunk) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+      for (int e = 0; e < 4; ++e) {
+        const float d0 = v[i][2 * e] - mean, d1 = v[i][2 * e + 1] - mean;
+        ss += d0 * d0; ss_odd += d1 * d1;
+      }
     }
   }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)p.D + p.eps);
+  const float rstd = rsqrtf(wave_sum(ss + ss_odd) / (float)p.D + p.eps);
   const bf16_t* shift = nullptr; const bf16_t* scale = nullptr;
   if (p.mod) {
     const int bb = r / p.rows_per_batch;
@@ -117,6 +121,108 @@ __global__ __launch_bounds__(256) void ld_layernorm_kernel(LnParams p) {
   }
 }
 
+// The DiT's hot form of the kernel above (bf16 in / out, affine weights, AdaLN modulation): the same operations at the same
+// roundings, arranged for VALU issue count -- the general kernel spends ~25 VALU operations per element, more issue time
+// than the row's HBM time; this one ~11:
+//  * element PAIRS: one v_cvt_pk_bf16_f32 per bf16 rounding of two elements, v_pk_{add,mul,fma}_f32 for the arithmetic (a
+//    bf16 pair unpacks into an adjacent register pair);
+//  * TWO rows per wave: the four per-column vectors (weight, bias, shift, scale) are loaded and unpacked once for both.
+// The statistics are summed per pair lane (even / odd elements) and combined at the end.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t unpack_bf16x2(uint32_t w) { return (f32x2_t){bf_lo(w), bf_hi(w)}; }
+__device__ __forceinline__ f32x2_t rbf2(f32x2_t a) { return unpack_bf16x2(pack_bf16x2(a[0], a[1])); }
+
+template <int NC, bool SAME>
+__device__ __forceinline__ void ln_mod2_apply(const LnParams& p, f32x2_t (&v)[2][NC][4], const float (&rstd)[2], const bf16_t* const (&shift)[2],
+                                              const bf16_t* const (&scale)[2], int r0, bool has1, int lane, int nchunk) {
+  const f32x2_t one2 = {1.0f, 1.0f};
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c >= nchunk) continue;
+    const u32x4_t ww = *(const u32x4_t*)(p.w + c * 8), bw = *(const u32x4_t*)(p.b + c * 8);
+    u32x4_t sh[2], sc[2];
+    sh[0] = *(const u32x4_t*)(shift[0] + c * 8); sc[0] = *(const u32x4_t*)(scale[0] + c * 8);
+    if (!SAME) { sh[1] = *(const u32x4_t*)(shift[1] + c * 8); sc[1] = *(const u32x4_t*)(scale[1] + c * 8); }
+    u32x4_t o[2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x2_t w2 = unpack_bf16x2(ww[e]), b2 = unpack_bf16x2(bw[e]);
+      f32x2_t sp[2], st[2];
+#pragma unroll
+      for (int j = 0; j < (SAME ? 1 : 2); ++j) {
+        sp[j] = rbf2(unpack_bf16x2(sc[j][e]) + one2);
+        st[j] = unpack_bf16x2(sh[j][e]);
+      }
+      if (SAME) { sp[1] = sp[0]; st[1] = st[0]; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x2_t rs = {rstd[j], rstd[j]};
+        f32x2_t y = rbf2(v[j][i][e] * rs * w2 + b2);              // LayerNorm output in bf16
+        // modulate(): x * (1 + scale) + shift, every op in bf16 as in the reference (dit_video_concat.py:388)
+        y = rbf2(y * sp[j]) + st[j];
+        o[j][e] = pack_bf16x2(y[0], y[1]);
+      }
+    }
+    *(u32x4_t*)((bf16_t*)p.out + (long)r0 * p.ldo + c * 8) = o[0];
+    if (has1) *(u32x4_t*)((bf16_t*)p.out + (long)(r0 + 1) * p.ldo + c * 8) = o[1];
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void ld_layernorm_mod_kernel(LnParams p) {
+  const int lane = threadIdx.x & 63;
+  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  if (r0 >= p.rows) return;
+  const bool has1 = r0 + 1 < p.rows;
+  const int nchunk = p.D >> 3;
+  u32x4_t raw[2][NC];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bf16_t* xr = (const bf16_t*)p.x + (long)(r0 + (has1 ? j : 0)) * p.ldx;      // odd row count: the last wave does its row twice
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      raw[j][i] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (c < nchunk) raw[j][i] = *(const u32x4_t*)(xr + c * 8);
+    }
+  }
+  const bf16_t* shift[2]; const bf16_t* scale[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = r0 + (has1 ? j : 0);
+    const int bb = r / p.rows_per_batch;
+    const bool txt = (r - bb * p.rows_per_batch) < p.text_len;
+    shift[j] = p.mod + bb * p.mod_bstride + (txt ? p.shift_txt : p.shift_img);
+    scale[j] = p.mod + bb * p.mod_bstride + (txt ? p.scale_txt : p.scale_img);
+  }
+  f32x2_t v[2][NC][4];
+  float rstd[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    f32x2_t s2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[j][i][e] = unpack_bf16x2(raw[j][i][e]); s2 += v[j][i][e]; }      // chunks past the row are zeros
+    const float mean = wave_sum(s2[0] + s2[1]) / (float)p.D;
+    const f32x2_t mean2 = {mean, mean};
+    f32x2_t ss2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      if (lane + 64 * i < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[j][i][e] -= mean2; ss2 += v[j][i][e] * v[j][i][e]; }
+      }
+    }
+    rstd[j] = rsqrtf(wave_sum(ss2[0] + ss2[1]) / (float)p.D + p.eps);
+  }
+  const bf16_t* const shc[2] = {shift[0], shift[1]};
+  const bf16_t* const scc[2] = {scale[0], scale[1]};
+  if (shift[0] == shift[1] && scale[0] == scale[1]) ln_mod2_apply<NC, true>(p, v, rstd, shc, scc, r0, has1, lane, nchunk);
+  else ln_mod2_apply<NC, false>(p, v, rstd, shc, scc, r0, has1, lane, nchunk);
+}
+
 // LayerNorm (+ modulate) with MXFP8 output: the activation of the next MXFP8 GEMM is quantised where it is produced.
 template <int NC>   // chunks (of 8 elements) per lane
 __global__ __launch_bounds__(256) void ld_layernorm_mx_kernel(LnParams p, unsigned char* mxs, long lds) {
@@ -126,7 +232,7 @@ __global__ __launch_bounds__(256) void ld_layernorm_mx_kernel(LnParams p, unsign
   const int nchunk = p.D >> 3;
   float v[NC][8];
   float yv[NC][8], amaxv[NC];
-  float s = 0.f;
+  float s = 0.f, s_odd = 0.f;       // even / odd elements summed apart: the order of ld_layernorm_mod_kernel's packed sums
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
@@ -142,19 +248,22 @@ __global__ __launch_bounds__(256) void ld_layernorm_mx_kernel(LnParams p, unsign
         for (int e = 0; e < 4; ++e) { v[i][2 * e] = bf_lo(a[e]); v[i][2 * e + 1] = bf_hi(a[e]); }
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[i][e];
+      for (int e = 0; e < 4; ++e) { s += v[i][2 * e]; s_odd += v[i][2 * e + 1]; }
     }
   }
-  const float mean = wave_sum(s) / (float)p.D;
-  float ss = 0.f;
+  const float mean = wave_sum(s + s_odd) / (float)p.D;
+  float ss = 0.f, ss_odd = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     if (lane + 64 * i < nchunk) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+      for (int e = 0; e < 4; ++e) {
+        const float d0 = v[i][2 * e] - mean, d1 = v[i][2 * e + 1] - mean;
+        ss += d0 * d0; ss_odd += d1 * d1;
+      }
     }
   }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)p.D + p.eps);
+  const float rstd = rsqrtf(wave_sum(ss + ss_odd) / (float)p.D + p.eps);
   const bf16_t* shift = nullptr; const bf16_t* scale = nullptr;
   if (p.mod) {
     const int bb = r / p.rows_per_batch;
@@ -481,6 +590,17 @@ LD_API int ld_layernorm(const void* x, int64_t ldx, int32_t x_f32, const void* w
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int nc = (int)((D / 8 + 63) / 64);
+  static const bool fast_ok = !(getenv("LD_LN_FAST") && atoi(getenv("LD_LN_FAST")) == 0);
+  if (fast_ok && mod && w && !x_f32 && !out_f32 && nc <= 4) {        // the DiT's block LayerNorms: two rows per wave
+    grid = dim3((unsigned)((rows + 7) / 8));
+    switch (nc) {
+      case 1: hipLaunchKernelGGL(ld_layernorm_mod_kernel<1>, grid, block, 0, st, p); break;
+      case 2: hipLaunchKernelGGL(ld_layernorm_mod_kernel<2>, grid, block, 0, st, p); break;
+      case 3: hipLaunchKernelGGL(ld_layernorm_mod_kernel<3>, grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL(ld_layernorm_mod_kernel<4>, grid, block, 0, st, p); break;
+    }
+    return ld_check_launch("ld_layernorm");
+  }
   switch (nc) {
     case 1: hipLaunchKernelGGL(ld_layernorm_kernel<1>, grid, block, 0, st, p); break;
     case 2: hipLaunchKernelGGL(ld_layernorm_kernel<2>, grid, block, 0, st, p); break;

@@ -50,6 +50,31 @@ for (B, H, N) in [(1, 2, 1122), (2, 1, 1400), (1, 1, 2175)]:
 print("WORST", worst)
 ''' % ROOT
 
+LN_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from landiff_amd import ops
+torch.manual_seed(0)
+dev, BF = "cuda", torch.bfloat16
+worst = 0.0
+def ref(x, w, b, ada, d, rpb, tl, eps=1e-5):          # torch restatement: LayerNorm in fp32 -> bf16, modulate() in bf16 ops
+    y = torch.nn.functional.layer_norm(x.float(), (d,), w.float(), b.float(), eps).to(BF)
+    r = torch.arange(x.shape[0], device=dev)
+    bb = r // rpb; txt = (r - bb * rpb) < tl
+    sh = torch.where(txt[:, None], ada[bb, 6 * d:7 * d], ada[bb, 0:d]); sc = torch.where(txt[:, None], ada[bb, 7 * d:8 * d], ada[bb, d:2 * d])
+    return y * (1 + sc) + sh
+# (rows, D, rows_per_batch, text_len): even / odd row counts, region and batch boundaries inside a row pair, every chunk count
+for rows, d, rpb, tl in [(666, 1920, 333, 7), (667, 1920, 334, 6), (5, 1920, 1 << 30, 0), (64, 128, 32, 3), (33, 768, 17, 4), (40, 1536, 20, 20)]:
+    x = (torch.randn(rows, d, device=dev) * 2 + 0.5).to(BF)
+    w = (1 + 0.1 * torch.randn(d, device=dev)).to(BF); b = (0.1 * torch.randn(d, device=dev)).to(BF)
+    ada = (0.3 * torch.randn((rows + rpb - 1) // rpb, 12 * d, device=dev)).to(BF)
+    o = torch.empty_like(x)
+    ops.layernorm(x, w, b, o, 1e-5, mod=ada, mod_bstride=12 * d, rows_per_batch=rpb, text_len=tl, shift_img=0, scale_img=d, shift_txt=6 * d, scale_txt=7 * d)
+    r = ref(x, w, b, ada, d, rpb, tl).float()
+    worst = max(worst, ((o.float() - r).abs() / (r.abs() + 1.0)).max().item())
+print("WORST", worst)
+""" % ROOT
+
 
 def _run(snippet, env):
     e = dict(os.environ); e.update(env)
@@ -70,6 +95,13 @@ def test_gemm_main_loop_variants(cuda, env):
                                  {"LD_ATTN_MSUM": "0"}, {"LD_ATTN_MSUM": "0", "LD_ATTN_SAFE": "1"}])
 def test_attention_variants(cuda, env):
     assert _run(ATTN_SNIPPET, env) < 2e-2
+
+
+@pytest.mark.parametrize("env", [{}, {"LD_LN_FAST": "0"}])
+def test_layernorm_modulate_forms(cuda, env):
+    """The DiT's LayerNorm + modulate: the two-rows-per-wave pair kernel (default) and the general kernel (LD_LN_FAST=0)
+    against a torch restatement -- at most one bf16 step apart (the kernels round where the reference's bf16 ops round)."""
+    assert _run(LN_SNIPPET, env) < 2 ** -7
 
 
 def test_gemv_streaming_loop_variant(cuda):

@@ -15,3 +15,16 @@ for _ in range(50): fn()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 50
 print(f"layernorm+modulate: {ms * 1e3:.1f} us  {2 * M * d * 2 / ms / 1e9:.2f} TB/s  checksum {out.float().sum().item():.4f}")
+# odd row count, text/image boundary inside a row pair, odd text length: the two-rows-per-wave form against a torch restatement
+def ref(x, w, b, ada, rpb, tl, eps=1e-5):
+    xf = x.float()
+    y = torch.nn.functional.layer_norm(xf, (d,), w.float(), b.float(), eps).to(torch.bfloat16)
+    r = torch.arange(x.shape[0], device=x.device)
+    bb = r // rpb; txt = (r - bb * rpb) < tl
+    sh = torch.where(txt[:, None], ada[bb, 6 * d:7 * d], ada[bb, 0:d]); sc = torch.where(txt[:, None], ada[bb, 7 * d:8 * d], ada[bb, d:2 * d])
+    return y * (1 + sc) + sh
+for rows, rpb, tl in [(2 * 333, 333, 7), (2 * 334 - 1, 334, 6), (5, 1 << 30, 0)]:
+    xs = x[:rows].contiguous(); o = torch.empty_like(xs)
+    ops.layernorm(xs, w, b, o, 1e-5, mod=ada, mod_bstride=12 * d, rows_per_batch=rpb, text_len=tl, shift_img=0, scale_img=d, shift_txt=6 * d, scale_txt=7 * d)
+    err = (o.float() - ref(xs, w, b, ada, rpb, tl).float()).abs().max().item()
+    print(f"rows={rows} rows_per_batch={rpb} text_len={tl}: max |diff| vs torch {err:.4f}")
