@@ -251,15 +251,15 @@ __device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = rbf(v[e] + bias[e]);                  // bf16 Linear output
-          if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_MX) x = act_gelu_tanh(x);
+        for (int e = 0; e < 4; ++e) {                       // element pairs: one cvt_pk per bf16 rounding of two values
+          ld_f32x2_t x = rbf2((ld_f32x2_t){v[2 * e], v[2 * e + 1]} + (ld_f32x2_t){bias[2 * e], bias[2 * e + 1]});      // bf16 Linear output
+          if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_MX) x = (ld_f32x2_t){act_gelu_tanh(x[0]), act_gelu_tanh(x[1])};
           if constexpr (EPI == EPI_GATE) {
-            x = rbf(x * ((e & 1) ? bf_hi(g[ps][e >> 1]) : bf_lo(g[ps][e >> 1])));
-            x = rbf(((e & 1) ? bf_hi(rs[ps][e >> 1]) : bf_lo(rs[ps][e >> 1])) + x);
-            if (p.add2) x = rbf(x + ((e & 1) ? bf_hi(ad[ps][e >> 1]) : bf_lo(ad[ps][e >> 1])));   // pack below rounds again: idempotent
+            x = rbf2(x * unpack_bf16x2(g[ps][e]));
+            x = unpack_bf16x2(rs[ps][e]) + x;               // rounded by the pack below (or here, when another term follows)
+            if (p.add2) x = rbf2(x) + unpack_bf16x2(ad[ps][e]);
           }
-          v[e] = x;
+          v[2 * e] = x[0]; v[2 * e + 1] = x[1];
         }
         if constexpr (EPI == EPI_GELU_MX) {
           // the bf16 activation, quantised where it is produced: a 32-column MX block is the 8 columns of four adjacent

@@ -128,9 +128,7 @@ __global__ __launch_bounds__(256) void ld_layernorm_kernel(LnParams p) {
 //    bf16 pair unpacks into an adjacent register pair);
 //  * TWO rows per wave: the four per-column vectors (weight, bias, shift, scale) are loaded and unpacked once for both.
 // The statistics are summed per pair lane (even / odd elements) and combined at the end.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t unpack_bf16x2(uint32_t w) { return (f32x2_t){bf_lo(w), bf_hi(w)}; }
-__device__ __forceinline__ f32x2_t rbf2(f32x2_t a) { return unpack_bf16x2(pack_bf16x2(a[0], a[1])); }
+typedef ld_f32x2_t f32x2_t;
 
 template <int NC, bool SAME>
 __device__ __forceinline__ void ln_mod2_apply(const LnParams& p, f32x2_t (&v)[2][NC][4], const float (&rstd)[2], const bf16_t* const (&shift)[2],
