@@ -70,6 +70,15 @@ __device__ __forceinline__ float act_gelu_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * u);   // exp(-2u)
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// the same operations on an element pair (v_pk_mul / v_pk_fma for the polynomial; the two transcendentals stay scalar)
+__device__ __forceinline__ ld_f32x2_t act_gelu_tanh2(ld_f32x2_t x) {
+  const ld_f32x2_t kBeta = {0.7978845608028654f, 0.7978845608028654f}, kKappa = {0.044715f, 0.044715f};
+  const ld_f32x2_t kExp = {-2.8853900817779268f, -2.8853900817779268f}, one = {1.0f, 1.0f};
+  const ld_f32x2_t u = kBeta * (x + kKappa * x * x * x);
+  const ld_f32x2_t a = kExp * u;
+  const ld_f32x2_t d = one + (ld_f32x2_t){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  return x * (ld_f32x2_t){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
 __device__ __forceinline__ float act_gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
 }

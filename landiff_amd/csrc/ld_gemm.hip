@@ -253,7 +253,7 @@ __device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                       // element pairs: one cvt_pk per bf16 rounding of two values
           ld_f32x2_t x = rbf2((ld_f32x2_t){v[2 * e], v[2 * e + 1]} + (ld_f32x2_t){bias[2 * e], bias[2 * e + 1]});      // bf16 Linear output
-          if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_MX) x = (ld_f32x2_t){act_gelu_tanh(x[0]), act_gelu_tanh(x[1])};
+          if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_MX) x = act_gelu_tanh2(x);
           if constexpr (EPI == EPI_GATE) {
             x = rbf2(x * unpack_bf16x2(g[ps][e]));
             x = unpack_bf16x2(rs[ps][e]) + x;               // rounded by the pack below (or here, when another term follows)
@@ -398,7 +398,11 @@ __device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&ac
         const f32x4_t hi = *(const f32x4_t*)(cw + row * CW_STRIDE + sub * 8 + 4);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = rbf(lo[e] + bias[e]); v[4 + e] = rbf(hi[e] + bias[4 + e]); }     // the bf16 Linear output
+        for (int e = 0; e < 2; ++e) {                    // the bf16 Linear output, rounded pairwise
+          const ld_f32x2_t a = rbf2((ld_f32x2_t){lo[2 * e], lo[2 * e + 1]} + (ld_f32x2_t){bias[2 * e], bias[2 * e + 1]});
+          const ld_f32x2_t c = rbf2((ld_f32x2_t){hi[2 * e], hi[2 * e + 1]} + (ld_f32x2_t){bias[4 + 2 * e], bias[5 + 2 * e]});
+          v[2 * e] = a[0]; v[2 * e + 1] = a[1]; v[4 + 2 * e] = c[0]; v[5 + 2 * e] = c[1];
+        }
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[e];
@@ -411,8 +415,10 @@ __device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&ac
         const float rstd = rsqrtf(ss * (1.0f / 64.0f) + p.qk_eps);
         u32x4_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o[e] = pack_bf16x2((v[2 * e] - mean) * rstd * wv[2 * e] + bv[2 * e], (v[2 * e + 1] - mean) * rstd * wv[2 * e + 1] + bv[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) {
+          const ld_f32x2_t m2 = {mean, mean}, r2 = {rstd, rstd};
+          o[e] = pack_bf16x2(((ld_f32x2_t){v[2 * e], v[2 * e + 1]} - m2) * r2 * (ld_f32x2_t){wv[2 * e], wv[2 * e + 1]} + (ld_f32x2_t){bv[2 * e], bv[2 * e + 1]});
+        }
         if (gm < p.M) {
           const int b = gm >= bnd ? b0 + 1 : b0;
           const int n = gm - b * p.Ntok;
