@@ -196,6 +196,7 @@ int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, cons
  * final LayerNorm (fp32) and the fp32 head -> logits [B][vocab].  Exactly the launches a caller would issue through
  * ld_llm_embed / ld_gemv / ld_llm_kv_attn / ld_layernorm_bf16_to_f32, queued from native code in one call: the
  * ~150 launches of a step are then bound by the GPU (~1.2 ms) and not by the host language's per-call overhead.
+ * emb_table == NULL: x already holds the embedding rows of the token (written by ld_llm_sample_advance).
  * All step state (*token, *pos) is read on the device; buffers are caller-owned: x/att [B][hidden], qkv [B][3*hidden],
  * gate [B][mlp] bf16, attn_ws B*heads*nsplit*130 floats, lnf_out [B][hidden] fp32, logits [B][vocab] fp32. */
 typedef struct ld_llm_layer {
@@ -220,6 +221,17 @@ int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B,
 int ld_llm_logits_to_probs(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided,
                            float scale, float temperature, const int32_t* pos, const int32_t* allowed,
                            int64_t allowed_stride, int32_t top_k, float top_p, void* stream);
+
+/* ld_llm_logits_to_probs, the draw, ld_llm_decode_advance and ld_llm_embed of the next token in one launch (the tail of a
+ * decode step: lm_model.py:417-508).  `noise` [V]: Exp(1) draws from the caller's generator -- torch.multinomial(p, 1, gen)
+ * IS argmax(p / empty_like(p).exponential_(1, gen)) (lowest index on ties), so the token equals the reference's draw from
+ * the same generator state.  probs / cfg_logits / sampled (the raw draw, before the forced-token override) are optional
+ * outputs; x [B][D] bf16 receives the embedding rows of *token (ld_llm_decode_forward then takes emb_table = NULL). */
+int ld_llm_sample_advance(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided, float scale,
+                          float temperature, int32_t* pos, const int32_t* allowed, int64_t allowed_stride,
+                          int32_t top_k, float top_p, const float* noise, const int32_t* forced, int64_t* token,
+                          int64_t* out_tokens, int32_t* out_count, int64_t* sampled, const float* emb_table, void* x,
+                          int64_t B, int64_t D, void* stream);
 
 /* After torch.multinomial: forced-token override (forced[*pos + 1] >= 0), record sampled visual tokens, ++*pos
  * (the elif chain of lm_model.py:455-508). */

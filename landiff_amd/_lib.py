@@ -75,6 +75,7 @@ SIGNATURES: dict[str, list] = {
                               c_float, c_float, P],
     "ld_llm_logits_to_probs": [P, P, P, I64, I32, c_float, c_float, P, P, I64, I32, c_float, P],
     "ld_llm_decode_advance": [P, P, P, P, P, P, P],
+    "ld_llm_sample_advance": [P, P, P, I64, I32, c_float, c_float, P, P, I64, I32, c_float, P, P, P, P, P, P, P, P, I64, I64, P],
     "ld_layernorm": [P, I64, I32, P, P, P, I64, I32, I64, I64, c_float, P, I64, I64, I64, I64, I64, I64, I64, P],
     "ld_qkv_split": [P, P, P, P, I64, I64, I64, I64, I32, P, P, P, P, c_float, P, P, P],
     "ld_groupnorm_stats_blocks": [I64],

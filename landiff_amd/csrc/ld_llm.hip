@@ -766,11 +766,22 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red, int tid, in
   for (int w = 0; w < (nthreads >> 6); ++w) tot += red[w];
   return tot;
 }
+// SAMPLE: the rest of the step in the same launch -- the draw that torch.multinomial makes for one sample,
+// argmax_i(probs[i] / q[i]) with q ~ Exp(1) from the caller's generator (`noise`; ATen's multinomial is exactly
+// empty_like(p).exponential_(1, gen), div, argmax: ties -> lowest index), the forced-token schedule / token record /
+// position advance of ld_decode_advance_kernel, and the embedding rows of the token the next step starts from.
+struct SampleArgs {
+  const float* noise;      // [V] Exp(1) draws
+  const int* forced; int* pos; long* token; long* out_tokens; int* out_count; long* sampled;
+  const float* emb; bf16_t* x; int B, D;
+};
+template <bool SAMPLE>
 __global__ __launch_bounds__(1024) void ld_logits_to_probs_kernel(const float* logits, float* probs, float* cfg_logits,
                                                                   int V, int guided, float scale, float temperature,
                                                                   const int* pos_ptr, const int* allowed, int n_allowed_stride,
-                                                                  int top_k, float top_p) {
+                                                                  int top_k, float top_p, SampleArgs sa) {
   __shared__ float red[32];
+  __shared__ int redi[32];
   __shared__ float sv[LD_SAMPLE_MAXV];     // value per vocabulary id
   __shared__ float ss[LD_SAMPLE_MAXV];     // values in descending order (top-p)
   __shared__ float thr_s;
@@ -847,7 +858,39 @@ __global__ __launch_bounds__(1024) void ld_logits_to_probs_kernel(const float* l
     for (int i = tid; i < V; i += nt) sv[i] = sv[i] / kept;
     __syncthreads();
   }
-  for (int i = tid; i < V; i += nt) probs[i] = sv[i];
+  for (int i = tid; i < V; i += nt) if (probs) probs[i] = sv[i];
+  if constexpr (SAMPLE) {
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += nt) {
+      const float r = sv[i] / sa.noise[i];                   // IEEE division, as at::div
+      if (r > best || (r == best && i < bi) || bi == 0x7fffffff) { best = r; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < (nt >> 6); ++w)
+        if (red[w] > best || (red[w] == best && redi[w] < bi)) { best = red[w]; bi = redi[w]; }
+      // ld_decode_advance_kernel: the token generated now sits at position pos + 1
+      const int pos = *sa.pos;
+      const int f = sa.forced[pos + 1];
+      long t = bi;
+      if (sa.sampled) *sa.sampled = t;
+      if (f >= 0) t = f;
+      else { sa.out_tokens[*sa.out_count] = t; *sa.out_count = *sa.out_count + 1; }
+      *sa.token = t;
+      *sa.pos = pos + 1;
+      redi[0] = (int)t;
+    }
+    __syncthreads();
+    const long t = redi[0];
+    for (int i = tid; i < sa.B * sa.D; i += nt) sa.x[i] = f2bf(sa.emb[t * sa.D + (i % sa.D)]);      // ld_embed_kernel
+  }
 }
 
 // after torch.multinomial: apply the forced-token schedule, record the sampled token, advance position
@@ -1022,11 +1065,11 @@ LD_API int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, c
                                  float* lnf_out, const float* head_w, float* logits, int64_t B, int64_t hidden,
                                  int64_t heads, int64_t mlp, int64_t vocab, int64_t Lmax, int64_t nsplit, float rms_eps,
                                  float ln_eps, void* stream) {
-  LD_REQUIRE(layers && n_layers > 0 && emb_table && token && pos && x && qkv && att && gate && attn_ws && cos_t && sin_t &&
+  LD_REQUIRE(layers && n_layers > 0 && (emb_table == nullptr || token) && pos && x && qkv && att && gate && attn_ws && cos_t && sin_t &&
              lnf_w && lnf_b && lnf_out && head_w && logits, "ld_llm_decode_forward: null pointer");
   LD_REQUIRE(hidden == heads * 128, "ld_llm_decode_forward: head_dim must be 128 (hidden=%ld heads=%ld)", (long)hidden, (long)heads);
   LD_REQUIRE(nsplit > 1, "ld_llm_decode_forward: the decode path is the key-split attention (nsplit > 1)");
-  int rc = ld_llm_embed(emb_table, token, x, B, hidden, stream);
+  int rc = emb_table ? ld_llm_embed(emb_table, token, x, B, hidden, stream) : 0;      // null: x already holds the token's embedding rows
   for (int64_t i = 0; i < n_layers && rc == 0; ++i) {
     const ld_llm_layer& w = layers[i];
     LD_REQUIRE(w.wqkv && w.wo && w.w1 && w.w3 && w.w2 && w.n0 && w.n1 && w.k_cache && w.v_cache,
@@ -1055,10 +1098,25 @@ LD_API int ld_llm_logits_to_probs(const float* logits, float* probs, float* cfg_
                                   int64_t allowed_stride, int32_t top_k, float top_p, void* stream) {
   LD_REQUIRE(logits && probs && V > 0 && V <= LD_SAMPLE_MAXV, "ld_llm_logits_to_probs: bad args (V=%ld, max %d)", (long)V, LD_SAMPLE_MAXV);
   LD_REQUIRE(!allowed || pos, "ld_llm_logits_to_probs: allowed table needs pos");
-  hipLaunchKernelGGL(ld_logits_to_probs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, probs, cfg_logits,
+  hipLaunchKernelGGL(ld_logits_to_probs_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, probs, cfg_logits,
                      (int)V, guided, scale, temperature, (const int*)pos, (const int*)allowed, (int)allowed_stride,
-                     (int)top_k, top_p);
+                     (int)top_k, top_p, SampleArgs{});
   return ld_check_launch("ld_llm_logits_to_probs");
+}
+
+LD_API int ld_llm_sample_advance(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided, float scale,
+                                 float temperature, int32_t* pos, const int32_t* allowed, int64_t allowed_stride,
+                                 int32_t top_k, float top_p, const float* noise, const int32_t* forced, int64_t* token,
+                                 int64_t* out_tokens, int32_t* out_count, int64_t* sampled, const float* emb_table, void* x,
+                                 int64_t B, int64_t D, void* stream) {
+  LD_REQUIRE(logits && V > 0 && V <= LD_SAMPLE_MAXV, "ld_llm_sample_advance: bad args (V=%ld, max %d)", (long)V, LD_SAMPLE_MAXV);
+  LD_REQUIRE(pos && noise && forced && token && out_tokens && out_count && emb_table && x, "ld_llm_sample_advance: null pointer");
+  SampleArgs sa{noise, (const int*)forced, (int*)pos, (long*)token, (long*)out_tokens, (int*)out_count, (long*)sampled,
+                emb_table, (bf16_t*)x, (int)B, (int)D};
+  hipLaunchKernelGGL(ld_logits_to_probs_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, probs, cfg_logits,
+                     (int)V, guided, scale, temperature, (const int*)pos, (const int*)allowed, (int)allowed_stride,
+                     (int)top_k, top_p, sa);
+  return ld_check_launch("ld_llm_sample_advance");
 }
 
 LD_API int ld_llm_decode_advance(const int64_t* sampled, const int32_t* forced, int32_t* pos, int64_t* token,

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import math
 
+import os
 import time
 
 import torch
@@ -116,6 +117,10 @@ class LLMRunner:
         self.logits = e(B, c.vocab, dt=torch.float32)
         self.probs = e(1, c.vocab, dt=torch.float32)
         self.cfg_logits = e(1, c.vocab, dt=torch.float32)
+        self.noise = e(1, c.vocab, dt=torch.float32)       # Exp(1) draws of the step's torch.multinomial (see _sample_and_advance)
+        # LD_LLM_FUSED_TAIL=0 (read once): sampling through torch.multinomial + ld_llm_decode_advance + ld_llm_embed (13 + 3 launches)
+        self.fused_tail = os.environ.get("LD_LLM_FUSED_TAIL", "1") != "0"
+        self._x_from_tail = False                          # the sampling launch has left the next token's embedding in self.x
         # split-K decode attention: >= one workgroup per CU, and at most 256 keys per split (ld_llm_kv_attn)
         self.nsplit = max(1, 256 // (B * H), -(-self.Lmax // 256))
         self.top_k, self.top_p = None, None
@@ -189,7 +194,7 @@ class LLMRunner:
         c = self.cfg
         if self._layer_table is None:
             self._layer_table = ops.llm_layer_table(self.blocks, self.kc, self.vc)
-        ops.llm_decode_forward(self._layer_table, self.emb, self.token, self.pos, self.x, self.qkv, self.att, self.gate,
+        ops.llm_decode_forward(self._layer_table, None if self._x_from_tail else self.emb, self.token, self.pos, self.x, self.qkv, self.att, self.gate,
                                self.attn_ws, self.cos, self.sin, self.ln_w, self.ln_b, self.lnf, self.head, self.logits,
                                c.heads, self.Lmax, self.nsplit, c.rms_eps, c.ln_eps)
 
@@ -208,6 +213,17 @@ class LLMRunner:
         ops.gemv(self.lnf, self.head, self.logits)
 
     def _sample_and_advance(self, guided, scale, temperature, generator):
+        """lm_model.py:417-508: CFG / temperature / restriction / filters -> probabilities -> one multinomial draw -> forced-token
+        schedule, token record, position advance.  torch.multinomial(p, 1, generator) is argmax(p / q) with
+        q = empty_like(p).exponential_(1, generator) (ATen's own formula; its other ten launches are validity checks), so the
+        draw is taken inside ld_llm_sample_advance from q drawn here with the same generator: the same token from the same
+        generator state (tests/test_gpu_stages.py::test_fused_sampling_equals_torch_multinomial), in 2 launches instead of 16."""
+        if self._x_from_tail:
+            self.noise.exponential_(1.0, generator=generator)
+            ops.llm_sample_advance(self.logits, self.probs, self.cfg_logits, guided, scale, temperature, self.pos, self.allowed,
+                                   self.noise, self.forced, self.token, self.out_tokens, self.out_count, self.sampled, self.emb,
+                                   self.x, top_k=self.top_k, top_p=self.top_p)
+            return
         ops.llm_logits_to_probs(self.logits, self.probs, self.cfg_logits, guided, scale, temperature, self.pos, self.allowed,
                                 top_k=self.top_k, top_p=self.top_p)
         torch.multinomial(self.probs, num_samples=1, generator=generator, out=self.sampled)
@@ -253,6 +269,7 @@ class LLMRunner:
             al[p, 0] = len(ids)
             al[p, 1:1 + len(ids)] = torch.tensor(ids, dtype=torch.int32)
         self.forced.copy_(ft); self.allowed.copy_(al)
+        self._x_from_tail = self.fused_tail and teacher_fed is None          # (a teacher-fed token is written by the host: re-embed it)
         self.out_count.zero_()
         if generator is None and seed:
             generator = torch.Generator(device=dev)

@@ -288,6 +288,21 @@ def llm_logits_to_probs(logits, probs, cfg_logits, guided, scale, temperature, p
           "ld_llm_logits_to_probs")
 
 
+def llm_sample_advance(logits, probs, cfg_logits, guided, scale, temperature, pos, allowed, noise, forced, token, out_tokens,
+                       out_count, sampled, emb, x, top_k=None, top_p=None):
+    """probabilities -> draw (argmax(p / noise), noise ~ Exp(1): torch.multinomial's own formula) -> forced-token schedule,
+    token record, position advance -> embedding rows of the next token in x: the tail of a decode step in one launch."""
+    V = logits.shape[-1]
+    B, D = x.shape
+    check(_lib.load().ld_llm_sample_advance(_ptr(logits), _ptr(probs), _ptr(cfg_logits), V, int(guided), float(scale),
+                                            float(temperature), _ptr(pos), _ptr(allowed),
+                                            allowed.stride(0) if allowed is not None else 0,
+                                            int(top_k) if top_k is not None else 0,
+                                            float(top_p) if top_p is not None else -1.0, _ptr(noise), _ptr(forced),
+                                            _ptr(token), _ptr(out_tokens), _ptr(out_count), _ptr(sampled), _ptr(emb),
+                                            _ptr(x), B, D, _stream()), "ld_llm_sample_advance")
+
+
 def llm_decode_advance(sampled, forced, pos, token, out_tokens, out_count):
     check(_lib.load().ld_llm_decode_advance(_ptr(sampled), _ptr(forced), _ptr(pos), _ptr(token), _ptr(out_tokens),
                                             _ptr(out_count), _stream()), "ld_llm_decode_advance")

@@ -427,3 +427,42 @@ def test_streaming_overlapped_decode_equals_serial(cuda, setup):
     over = pipe.generate_stream(inp, 3, prefix_frames=1)
     assert "llm_overlapped" in pipe.timings
     assert torch.equal(serial, over)
+
+
+def test_fused_sampling_equals_torch_multinomial(cuda):
+    """ld_llm_sample_advance draws argmax(p / q), q = exponential_(1, generator): the token torch.multinomial(p, 1, generator)
+    returns from the same generator state (lm_model.py:450-454), draw after draw; and it leaves the schedule state
+    (position, fed-back token, recorded tokens) and the next token's embedding rows as the three separate launches do."""
+    from landiff_amd import ops
+    V, D, B, n = 2055, 256, 2, 300
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(V, D, generator=g).to(cuda)
+    forced = torch.full((n + 4,), -1, dtype=torch.int32); forced[7] = 2050; forced[8] = 2051; forced[100] = 3
+    forced = forced.to(cuda)
+    st = []
+    for fused in (False, True):
+        gen = torch.Generator(device=cuda); gen.manual_seed(77)
+        glog = torch.Generator(device=cuda); glog.manual_seed(1)
+        pos = torch.zeros(1, device=cuda, dtype=torch.int32); token = torch.zeros(1, device=cuda, dtype=torch.int64)
+        out_tokens = torch.zeros(n + 4, device=cuda, dtype=torch.int64); out_count = torch.zeros(1, device=cuda, dtype=torch.int32)
+        sampled = torch.zeros(1, 1, device=cuda, dtype=torch.int64)
+        probs = torch.empty(1, V, device=cuda); cfg = torch.empty(1, V, device=cuda); noise = torch.empty(1, V, device=cuda)
+        x = torch.zeros(B, D, device=cuda, dtype=torch.bfloat16)
+        draws, xs = [], []
+        for it in range(n):
+            sharp = 0.5 + 6.0 * (it % 5)                                 # from near-uniform to peaked distributions
+            logits = torch.randn(2, V, device=cuda, generator=glog) * sharp
+            if fused:
+                noise.exponential_(1.0, generator=gen)
+                ops.llm_sample_advance(logits, probs, cfg, True, 7.5, 1.0, pos, None, noise, forced, token, out_tokens, out_count,
+                                       sampled, emb, x)
+            else:
+                ops.llm_logits_to_probs(logits, probs, cfg, True, 7.5, 1.0, pos, None)
+                torch.multinomial(probs, num_samples=1, generator=gen, out=sampled)
+                ops.llm_decode_advance(sampled, forced, pos, token, out_tokens, out_count)
+                ops.llm_embed(emb, token, x)
+            draws.append(sampled.clone()); xs.append(x.clone())
+        st.append((torch.cat(draws).cpu(), torch.stack(xs).cpu(), pos.cpu(), token.cpu(), out_tokens.cpu(), out_count.cpu(), probs.cpu()))
+    for a, b in zip(st[0], st[1]):
+        assert torch.equal(a, b)
+    assert int(st[0][5]) == n - 3 and len(set(st[0][0].reshape(-1).tolist())) > 50

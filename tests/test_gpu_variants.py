@@ -75,6 +75,28 @@ for rows, d, rpb, tl in [(666, 1920, 333, 7), (667, 1920, 334, 6), (5, 1920, 1 <
 print("WORST", worst)
 """ % ROOT
 
+LLM_SNIPPET = r"""
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from landiff_amd.config import PipelineConfig
+from landiff_amd.weights import init_pipeline_state
+from landiff_amd.llm import LLMRunner
+cfg = PipelineConfig.tiny(num_steps=3).check()
+c = cfg.llm
+st = init_pipeline_state(cfg, seed=1234, parts=["llm"])
+dev = torch.device("cuda:0")
+run = LLMRunner(st["llm"], c, dev, max_text=32, max_frames=c.segment_length)
+text = torch.randn(6, c.text_dim, generator=torch.Generator().manual_seed(4))
+h = hashlib.sha256()
+for seed, graph in ((21, False), (22, True)):
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    log = []
+    codes = run.sample(text, num_frames=c.segment_length, guidance_scale=7.5, generator=gen, logits_log=None if graph else log, use_graph=graph)
+    h.update(codes.cpu().numpy().tobytes())
+    if log: h.update(torch.cat(log, 0).cpu().numpy().tobytes())
+print("HASH", h.hexdigest())
+""" % ROOT
+
 
 def _run(snippet, env):
     e = dict(os.environ); e.update(env)
@@ -102,6 +124,18 @@ def test_layernorm_modulate_forms(cuda, env):
     """The DiT's LayerNorm + modulate: the two-rows-per-wave pair kernel (default) and the general kernel (LD_LN_FAST=0)
     against a torch restatement -- at most one bf16 step apart (the kernels round where the reference's bf16 ops round)."""
     assert _run(LN_SNIPPET, env) < 2 ** -7
+
+
+def test_llm_sampling_tail_forms(cuda):
+    """AR decode with the step's tail in one launch (default) or as torch.multinomial + ld_llm_decode_advance + ld_llm_embed
+    (LD_LLM_FUSED_TAIL=0): the same tokens and CFG logits from the same seeds, eager and graph-replayed."""
+    outs = []
+    for env in ({}, {"LD_LLM_FUSED_TAIL": "0"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", LLM_SNIPPET], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
+    assert outs[0] == outs[1]
 
 
 def test_gemv_streaming_loop_variant(cuda):
