@@ -571,6 +571,65 @@ __global__ __launch_bounds__(256) void ld_gn_apply_kernel(GnApplyParams p) {
   }
 }
 
+// The same operation for channel counts whose 16-byte chunks divide the workgroup (C / 8 | 256: every VAE / upsampler
+// width): one (frame-group, t, h) row of W positions per workgroup, thread -> fixed chunk, so the per-channel operands
+// (gamma, beta, the group's mean / rstd) are unpacked once per thread and no index needs a division except the nearest-
+// neighbour column of zq; element pairs for the bf16 roundings.  (The flat kernel above decomposes a 64-bit linear index
+// per chunk and divides by the group width per element: several times the arithmetic of the normalisation itself.)
+__global__ __launch_bounds__(256) void ld_gn_apply_rows_kernel(GnApplyParams p) {
+  const int chunks = p.C >> 3;
+  const int tid = threadIdx.x;
+  const int chunk = tid % chunks, wstep = 256 / chunks;
+  const int row = blockIdx.x;                         // (f, t, h)
+  const int h = row % p.H, ft = row / p.H;
+  const int t = ft % p.T, f = ft / p.T;
+  const int cpg = p.C / p.G;
+  ld_f32x2_t mean2[4], rstd2[4], gm2[4], bt2[4];
+  {
+    const u32x4_t gw = *(const u32x4_t*)(p.gamma + chunk * 8), bw = *(const u32x4_t*)(p.beta + chunk * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      gm2[e] = unpack_bf16x2(gw[e]); bt2[e] = unpack_bf16x2(bw[e]);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = f * p.G + (chunk * 8 + 2 * e + k) / cpg;
+        const double mean = p.stats[2 * i] * p.inv_count;
+        const double var = p.stats[2 * i + 1] * p.inv_count - mean * mean;
+        mean2[e][k] = (float)mean;
+        rstd2[e][k] = rsqrtf(fmaxf((float)var, 0.f) + p.eps);
+      }
+    }
+  }
+  int tz = 0, hz = 0;
+  if (p.zy) {
+    if (p.T > 1 && (p.T & 1)) tz = (t == 0) ? 0 : 1 + (int)(((long)(t - 1) * (p.Tz - 1)) / (p.T - 1));
+    else tz = (int)(((long)t * p.Tz) / p.T);
+    hz = (int)(((long)h * p.Hz) / p.H);
+  }
+  const bf16_t* xrow = p.x + (long)row * p.W * p.C + chunk * 8;
+  const long Tp = p.T + p.tpad, Hp = p.H + 2 * p.hpad, Wp = p.W + 2 * p.wpad;
+  bf16_t* orow = p.out + ((((long)f * Tp + t + p.tpad) * Hp + h + p.hpad) * Wp + p.wpad) * p.C + chunk * 8;
+  const bf16_t* zyrow = p.zy ? p.zy + ((long)tz * p.Hz + hz) * p.Wz * p.C + chunk * 8 : nullptr;
+  const bf16_t* zbrow = p.zy ? p.zb + ((long)tz * p.Hz + hz) * p.Wz * p.C + chunk * 8 : nullptr;
+  for (int w = tid / chunks; w < p.W; w += wstep) {
+    const u32x4_t a = *(const u32x4_t*)(xrow + (long)w * p.C);
+    u32x4_t yw = (u32x4_t){0u, 0u, 0u, 0u}, zw = yw;
+    if (p.zy) {
+      const int wz = (int)(((long)w * p.Wz) / p.W);
+      yw = *(const u32x4_t*)(zyrow + (long)wz * p.C); zw = *(const u32x4_t*)(zbrow + (long)wz * p.C);
+    }
+    u32x4_t ow;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ld_f32x2_t y = rbf2((unpack_bf16x2(a[e]) - mean2[e]) * rstd2[e] * gm2[e] + bt2[e]);      // GroupNorm output (bf16)
+      if (p.zy) y = rbf2(rbf2(y * unpack_bf16x2(yw[e])) + unpack_bf16x2(zw[e]));              // norm_f * conv_y(zq) + conv_b(zq)
+      if (p.swish) y = y * rbf2((ld_f32x2_t){1.0f / (1.0f + __expf(-y[0])), 1.0f / (1.0f + __expf(-y[1]))});   // x * sigmoid(x)
+      ow[e] = pack_bf16x2(y);
+    }
+    *(u32x4_t*)(orow + (long)w * p.C) = ow;
+  }
+}
+
 }  // namespace
 
 LD_API int ld_layernorm(const void* x, int64_t ldx, int32_t x_f32, const void* w, const void* b, void* out, int64_t ldo,
@@ -657,7 +716,11 @@ LD_API int ld_groupnorm_apply(const void* x, void* out_padded, const double* sta
   const long total = F * T * H * W * (C / 8);
   const long blocks = (total + 255) / 256;
   dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
-  hipLaunchKernelGGL(ld_gn_apply_kernel, grid, block, 0, (hipStream_t)stream, p);
+  static const bool rows_ok = !(getenv("LD_GN_ROWS") && atoi(getenv("LD_GN_ROWS")) == 0);
+  if (rows_ok && 256 % (C / 8) == 0 && F * T * H < (1l << 30))
+    hipLaunchKernelGGL(ld_gn_apply_rows_kernel, dim3((unsigned)(F * T * H)), block, 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(ld_gn_apply_kernel, grid, block, 0, (hipStream_t)stream, p);
   return ld_check_launch("ld_groupnorm_apply");
 }
 

@@ -97,6 +97,45 @@ for seed, graph in ((21, False), (22, True)):
 print("HASH", h.hexdigest())
 """ % ROOT
 
+GN_SNIPPET = r"""
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from landiff_amd import ops
+torch.manual_seed(0)
+dev, BF = "cuda", torch.bfloat16
+h = hashlib.sha256()
+worst = 0.0
+# (F, T, H, W, C, G, zq shape or None, pads, swish): odd T with zq (first-frame rule), even T, no zq, narrow groups, C = 768 (flat kernel)
+for F, T, H, W, C, G, zs, pads, swish in [(1, 3, 10, 12, 128, 32, (2, 5, 6), (2, 1, 1), True), (2, 2, 6, 9, 512, 32, (1, 3, 3), (0, 1, 1), True),
+                                           (3, 1, 7, 5, 64, 32, None, (0, 1, 1), True), (1, 5, 8, 8, 256, 32, (3, 2, 2), (2, 1, 1), False),
+                                           (1, 1, 4, 6, 768, 32, None, (0, 0, 0), True)]:
+    x = (torch.randn(F * T, H, W, C, device=dev) * 1.5 + 0.3).to(BF)
+    gamma = (1 + 0.2 * torch.randn(C, device=dev)).to(BF); beta = (0.2 * torch.randn(C, device=dev)).to(BF)
+    zy = zb = None
+    if zs:
+        zy = torch.randn(*zs, C, device=dev).to(BF); zb = torch.randn(*zs, C, device=dev).to(BF)
+    stats = torch.zeros(F, G, 2, device=dev, dtype=torch.float64)
+    ops.groupnorm_stats(x, stats, F, T * H * W, C, G)
+    tp, hp, wp = pads
+    out = torch.zeros(F, T + tp, H + 2 * hp, W + 2 * wp, C, device=dev, dtype=BF)
+    ops.groupnorm_apply(x, out, stats, gamma, beta, F, T, H, W, C, G, zy=zy, zb=zb, zshape=zs or (1, 1, 1), tpad=tp, hpad=hp, wpad=wp, swish=swish)
+    h.update(out.cpu().view(torch.int16).numpy().tobytes())
+    # torch restatement (GroupNorm in fp32 -> bf16, SpatialNorm terms and swish in bf16 ops)
+    xf = x.float().view(F, T, H, W, G, C // G)
+    mu = xf.mean(dim=(1, 2, 3, 5), keepdim=True); var = xf.var(dim=(1, 2, 3, 5), unbiased=False, keepdim=True)
+    y = (((xf - mu) * torch.rsqrt(var + 1e-6)).view(F, T, H, W, C) * gamma.float() + beta.float()).to(BF)
+    if zs:
+        ti = torch.tensor([0 if (T > 1 and (T & 1) and t == 0) else (1 + ((t - 1) * (zs[0] - 1)) // (T - 1) if (T > 1 and (T & 1)) else (t * zs[0]) // T) for t in range(T)], device=dev)
+        hi = (torch.arange(H, device=dev) * zs[1]) // H; wi = (torch.arange(W, device=dev) * zs[2]) // W
+        y = y * zy[ti][:, hi][:, :, wi] + zb[ti][:, hi][:, :, wi]
+    if swish:
+        y = y * torch.sigmoid(y)
+    got = out[:, tp:, hp:hp + H, wp:wp + W].float()
+    worst = max(worst, ((got - y.float()).abs() / (y.float().abs() + 1.0)).max().item())
+print("HASH", h.hexdigest())
+print("WORST", worst)
+""" % ROOT
+
 
 def _run(snippet, env):
     e = dict(os.environ); e.update(env)
@@ -124,6 +163,19 @@ def test_layernorm_modulate_forms(cuda, env):
     """The DiT's LayerNorm + modulate: the two-rows-per-wave pair kernel (default) and the general kernel (LD_LN_FAST=0)
     against a torch restatement -- at most one bf16 step apart (the kernels round where the reference's bf16 ops round)."""
     assert _run(LN_SNIPPET, env) < 2 ** -7
+
+
+def test_groupnorm_apply_forms(cuda):
+    """GroupNorm / SpatialNorm / swish: the row-per-workgroup kernel (default where C / 8 divides 256) and the flat kernel
+    (LD_GN_ROWS=0) are the same arithmetic -- equal bit for bit -- and within two bf16 steps of a torch restatement."""
+    outs = []
+    for env in ({}, {"LD_GN_ROWS": "0"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", GN_SNIPPET], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
+        assert float([l for l in r.stdout.splitlines() if l.startswith("WORST")][-1].split()[1]) < 2 ** -6
+    assert outs[0] == outs[1]
 
 
 def test_llm_sampling_tail_forms(cuda):
