@@ -53,7 +53,7 @@ def _close(out, ref):
 SHAPES = [  # (B, N, K, form)
     (2, 6144, 2048, "norm"), (2, 2048, 2048, "resid"), (2, 11008, 2048, "gated"), (2, 2048, 11008, "resid"),
     (1, 515, 2048, "norm"), (3, 1000, 1024, "bias_act"), (4, 129, 4096, "gated"), (2, 77, 8200, "resid"),
-    (1, 64, 512, "in_act"), (4, 3072, 512, "in_act"), (2, 30, 24576, "bias_act"), (3, 200, 11008, "resid"),
+    (1, 64, 512, "in_act"), (4, 3072, 512, "in_act"), (2, 23040, 512, "in_act"), (3, 4099, 256, "in_act"), (2, 5000, 384, "bias_act"), (2, 30, 24576, "bias_act"), (3, 200, 11008, "resid"),
 ]
 
 
