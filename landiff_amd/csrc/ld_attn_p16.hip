@@ -29,6 +29,11 @@
 namespace {
 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
+// timing experiments only (tools/attn_ablate.sh): bit 0 no exp2, 1 no fragment LDS reads (5: no V^T reads only, 6: no K reads only), 2 no LDS-DMA (7: every DMA reads tile 0, 8: no vmcnt wait at the period end, 9: no barrier there), 3 no P
+// packing, 4 no row-sum MFMAs in the main loop.  Results are wrong when any bit is set; the shipped library is built without the macro.
+#ifndef LD_ATTN_ABLATE
+#define LD_ATTN_ABLATE 0
+#endif
 
 __device__ __forceinline__ int swz_k(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
 
@@ -184,16 +189,17 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
       u32x4_t pw[2][2];                                          // P fragments [kg][qb]
       // E(v): score -> probability (tile j); N(v): the same on tile j+1 (MSUM); A(v): row-sum add (!MSUM); C(kg, qb, half): two
       // packed words of P fragment [kg][qb]
-      auto E = [&](int v) { EXPV(sc, v); };
-      auto N = [&](int v) { if (HAS_QK) EXPV(sn, v); };
+      auto E = [&](int v) { if (!(LD_ATTN_ABLATE & 1)) EXPV(sc, v); };
+      auto N = [&](int v) { if (HAS_QK && !(LD_ATTN_ABLATE & 1)) EXPV(sn, v); };
       auto A = [&](int v) { const int kb = v >> 3, qb = (v >> 2) & 1, r = v & 3; ls[qb][r & 1] += sc[kb][qb][r]; };
       auto C = [&](int kg, int qb, int half) {
+        if (LD_ATTN_ABLATE & 8) { pw[kg][qb][2 * half] = __float_as_uint(sc[2 * kg + half][qb][0]); pw[kg][qb][2 * half + 1] = __float_as_uint(sc[2 * kg + half][qb][2]); return; }
         pw[kg][qb][2 * half] = pack_bf16x2(sc[2 * kg + half][qb][0], sc[2 * kg + half][qb][1]);
         pw[kg][qb][2 * half + 1] = pack_bf16x2(sc[2 * kg + half][qb][2], sc[2 * kg + half][qb][3]);
       };
-      auto VF = [&](int g) { vf[g >> 1][g & 1] = *(const bf16x8_t*)(smem + vofs[g & 1] + vslot * KTILE_BYTES + (g >> 1) * 2048); };
+      auto VF = [&](int g) { if (!(LD_ATTN_ABLATE & (2 | 32))) vf[g >> 1][g & 1] = *(const bf16x8_t*)(smem + vofs[g & 1] + vslot * KTILE_BYTES + (g >> 1) * 2048); };
       auto KF = [&](int g) {                                      // g = kb*2 + ks
-        if (HAS_K2) kf[g >> 1][g & 1] = *(const bf16x8_t*)(smem + kofs[g & 1] + k2slot * KTILE_BYTES + (g >> 2) * 4096 + ((g >> 1) & 1) * 512);
+        if (HAS_K2 && !(LD_ATTN_ABLATE & (2 | 64))) kf[g >> 1][g & 1] = *(const bf16x8_t*)(smem + kofs[g & 1] + k2slot * KTILE_BYTES + (g >> 2) * 4096 + ((g >> 1) & 1) * 512);
       };
       auto QK = [&](int g) {                                      // g = ks*8 + kb*2 + qb
         const int ks = g >> 3, kb = (g >> 1) & 3, qb = g & 1;
@@ -204,10 +210,10 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
         o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[db][kg], __builtin_bit_cast(bf16x8_t, pw[kg][qb]), o[db][qb], 0, 0, 0);
       };
       auto SUM = [&](int kg, int qb) {
-        lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8_t, pw[kg][qb]), lacc[qb], 0, 0, 0);
+        if (!(LD_ATTN_ABLATE & 16)) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8_t, pw[kg][qb]), lacc[qb], 0, 0, 0);
       };
       auto DMA = [&](int g) {                 // piece g of the period's 2 * NPW
-        if (do_dma && g < 2 * NPW) dma_piece(g % NPW, g < NPW ? dslot0 : dslot1, g < NPW ? dt0 : dt1);
+        if (do_dma && g < 2 * NPW && !(LD_ATTN_ABLATE & 4)) dma_piece(g % NPW, g < NPW ? dslot0 : dslot1, (LD_ATTN_ABLATE & 128) ? 0 : (g < NPW ? dt0 : dt1));
       };
       if constexpr (MSUM) {
         // ---- phase 1: QK^T of tile j+1 (16 MFMAs) over exp2 of scores 18..31 of tile j, the packing of P[0][*], the V_j
@@ -292,8 +298,9 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
       }
       // ---- end of a period (odd iteration): retire this wave's LDS reads and DMA pieces, then the barrier ----
       if (!EVEN) {
-        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
+        if (LD_ATTN_ABLATE & 256) __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0) only
+        else __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0)
+        if (!(LD_ATTN_ABLATE & 512)) __builtin_amdgcn_s_barrier();
       }
       FENCE();
     };
@@ -308,6 +315,7 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
     qk_tile(sA, kf);
     FENCE();
     load_kf(kf, 1);
+    if (LD_ATTN_ABLATE & (2 | 32)) load_vf(vf, 0);
 #pragma unroll
     for (int v = 0; v < NPRE; ++v) EXPV(sA, v);
     __builtin_amdgcn_s_waitcnt(0x0070);
