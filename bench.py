@@ -23,9 +23,9 @@ import torch  # noqa: E402
 
 METRIC = "end-to-end frames/sec, 49f 480x720 @50 steps"
 # HBM bytes per attention launch at the headline shape from separate rocprofv3 --pmc passes
-# (profiles/r02_attn_p16_pmc_hbm.txt): (2 x FETCH_SIZE [gfx950 correction, MI355X_MICROARCH.md HBM] + WRITE_SIZE) x 1024
-# = (2 * 758000 + 133300) KiB.  Reported only when the run is that kernel at that shape.
-ATTN_TRAFFIC = {"kernel": "ld_attn_p16_w4_kernel", "bytes": (2 * 758000 + 133300) * 1024}
+# (profiles/r02_attn_q64_pmc_hbm.txt): (2 x FETCH_SIZE [gfx950 correction, MI355X_MICROARCH.md HBM] + WRITE_SIZE) x 1024
+# = (2 * 489400 + 141700) KiB.  Reported only when the run is that kernel at that shape.
+ATTN_TRAFFIC = {"kernel": "ld_attn_q64_kernel", "bytes": (2 * 489400 + 141700) * 1024}
 
 
 def cpu_baseline(cfg, budget_s: float = 25.0):
@@ -183,7 +183,7 @@ def main():
         kname = (_lib.load().ld_attn_last_kernel() or b"").decode()      # what the launcher actually ran (shape + LD_ATTN_* knobs)
         # the PMC traffic figure was collected on the default kernel at the headline shape only (profiles/, see ATTN_TRAFFIC)
         headline = (not args.tiny and not stream and not args.fp8_gemm and kname == ATTN_TRAFFIC["kernel"]
-                    and not any(os.environ.get(k) for k in ("LD_ATTN_NW", "LD_ATTN_SAFE", "LD_ATTN_VARIANT", "LD_ATTN_MSUM")))
+                    and not any(os.environ.get(k) for k in ("LD_ATTN_NW", "LD_ATTN_SAFE", "LD_ATTN_VARIANT", "LD_ATTN_MSUM", "LD_ATTN_Q64")))
         res = {
             "metric": METRIC, "value": world * n_frames * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

@@ -10,7 +10,7 @@ for s in $SRCS; do
   o=obj/${s%.hip}.o
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ ld_common.h -nt "$o" ] || [ ld_attn.h -nt "$o" ] || [ ../../include/landiff_hip.h -nt "$o" ]; then
     extra=""
-    { [ "$s" = "ld_attn_pipe.hip" ] || [ "$s" = "ld_attn_p16.hip" ]; } && extra="-fno-slp-vectorize"
+    { [ "$s" = "ld_attn_pipe.hip" ] || [ "$s" = "ld_attn_p16.hip" ] || [ "$s" = "ld_attn_q64.hip" ]; } && extra="-fno-slp-vectorize"
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result $extra -c "$s" -o "$o" &
     pids+=($!)
   fi

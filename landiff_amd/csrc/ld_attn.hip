@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
 
 int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st);   // ld_attn_pipe.hip
 int ld_attn_p16_launch(const AttnParams& p, hipStream_t st);     // ld_attn_p16.hip
+int ld_attn_q64_launch(const AttnParams& p, hipStream_t st);     // ld_attn_q64.hip
 
 // name of the kernel the calling thread's last ld_attn_fwd_bf16 launched (bench.py labels its roofline object with it)
 static thread_local const char* g_attn_last_kernel = "";
@@ -368,7 +369,7 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   dim3 grid((unsigned)(B * H * nqb)), block(256);
   static int var = -1;
   if (var < 0) {
-    // tuning knob: 0 = default (pipelined 16x16x32 kernel of ld_attn_p16.hip for every unmasked problem of >= 6 key tiles, else the plain kernel),
+    // tuning knob: 0 = default (pipelined 16x16x32 kernels of ld_attn_q64.hip / ld_attn_p16.hip for every unmasked problem of >= 6 key tiles, else the plain kernel),
     // 8 = the pipelined 32x32x16 kernel of ld_attn_pipe.hip (round-1 default), 9 = plain kernel everywhere,
     // 1 / 4 = plain kernel with row sums on the matrix pipe / lean-register 4-waves form
     const char* e = getenv("LD_ATTN_VARIANT");
@@ -377,6 +378,9 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   hipStream_t st = (hipStream_t)stream;
   const size_t s1 = 2 * STAGE_BYTES + 64;
   const int64_t nkt = (Nk + KT - 1) / KT;
+  // LD_ATTN_Q64=0 (tuning knob): the 32-query-row wave tile of ld_attn_p16.hip instead of the 64-row one of ld_attn_q64.hip
+  static const int q64 = getenv("LD_ATTN_Q64") ? atoi(getenv("LD_ATTN_Q64")) : 1;
+  if (var == 0 && !fid_k && nkt >= 6 && q64) return ld_attn_q64_launch(p, st);
   if (var == 0 && !fid_k && nkt >= 6) return ld_attn_p16_launch(p, st);                  // any tile count
   if (var == 8 && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {                              // (the round-1 kernel: tile counts 4 m + 2)
     return ld_attn_pipe2_launch(p, st);

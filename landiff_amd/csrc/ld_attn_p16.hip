@@ -30,7 +30,7 @@ namespace {
 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 // timing experiments only (tools/attn_ablate.sh): bit 0 no exp2, 1 no fragment LDS reads (5: no V^T reads only, 6: no K reads only), 2 no LDS-DMA (7: every DMA reads tile 0, 8: no vmcnt wait at the period end, 9: no barrier there), 3 no P
-// packing, 4 no row-sum MFMAs in the main loop.  Results are wrong when any bit is set; the shipped library is built without the macro.
+// packing, 10 / 11 / 12: every other K fragment read / V^T fragment read / DMA piece only (the traffic of a 64-query-row wave), 4 no row-sum MFMAs in the main loop.  Results are wrong when any bit is set; the shipped library is built without the macro.
 #ifndef LD_ATTN_ABLATE
 #define LD_ATTN_ABLATE 0
 #endif
@@ -197,8 +197,9 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
         pw[kg][qb][2 * half] = pack_bf16x2(sc[2 * kg + half][qb][0], sc[2 * kg + half][qb][1]);
         pw[kg][qb][2 * half + 1] = pack_bf16x2(sc[2 * kg + half][qb][2], sc[2 * kg + half][qb][3]);
       };
-      auto VF = [&](int g) { if (!(LD_ATTN_ABLATE & (2 | 32))) vf[g >> 1][g & 1] = *(const bf16x8_t*)(smem + vofs[g & 1] + vslot * KTILE_BYTES + (g >> 1) * 2048); };
+      auto VF = [&](int g) { if (!(LD_ATTN_ABLATE & (2 | 32)) && !((LD_ATTN_ABLATE & 2048) && (g & 1))) vf[g >> 1][g & 1] = *(const bf16x8_t*)(smem + vofs[g & 1] + vslot * KTILE_BYTES + (g >> 1) * 2048); };
       auto KF = [&](int g) {                                      // g = kb*2 + ks
+        if ((LD_ATTN_ABLATE & 1024) && (g & 1)) { asm volatile("" : "+v"(kf[g >> 1][g & 1])); return; }      // not re-read, but opaque: keeps the QK^T MFMAs in the loop
         if (HAS_K2 && !(LD_ATTN_ABLATE & (2 | 64))) kf[g >> 1][g & 1] = *(const bf16x8_t*)(smem + kofs[g & 1] + k2slot * KTILE_BYTES + (g >> 2) * 4096 + ((g >> 1) & 1) * 512);
       };
       auto QK = [&](int g) {                                      // g = ks*8 + kb*2 + qb
@@ -213,7 +214,7 @@ __device__ __forceinline__ void attn_p16_body(const AttnParams& p, int force_saf
         if (!(LD_ATTN_ABLATE & 16)) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8_t, pw[kg][qb]), lacc[qb], 0, 0, 0);
       };
       auto DMA = [&](int g) {                 // piece g of the period's 2 * NPW
-        if (do_dma && g < 2 * NPW && !(LD_ATTN_ABLATE & 4)) dma_piece(g % NPW, g < NPW ? dslot0 : dslot1, (LD_ATTN_ABLATE & 128) ? 0 : (g < NPW ? dt0 : dt1));
+        if (do_dma && g < 2 * NPW && !(LD_ATTN_ABLATE & 4) && !((LD_ATTN_ABLATE & 4096) && (g & 1))) dma_piece(g % NPW, g < NPW ? dslot0 : dslot1, (LD_ATTN_ABLATE & 128) ? 0 : (g < NPW ? dt0 : dt1));
       };
       if constexpr (MSUM) {
         // ---- phase 1: QK^T of tile j+1 (16 MFMAs) over exp2 of scores 18..31 of tile j, the packing of P[0][*], the V_j

@@ -151,9 +151,9 @@ def test_gemm_main_loop_variants(cuda, env):
     assert _run(GEMM_SNIPPET, env) < 1e-2
 
 
-@pytest.mark.parametrize("env", [{"LD_ATTN_SAFE": "1"}, {"LD_ATTN_NW": "8"}, {"LD_ATTN_NW": "8", "LD_ATTN_SAFE": "1"}, {"LD_ATTN_VARIANT": "9"}, {"LD_ATTN_VARIANT": "1"}, {"LD_ATTN_VARIANT": "4"},
+@pytest.mark.parametrize("env", [{"LD_ATTN_SAFE": "1"}, {"LD_ATTN_Q64": "0"}, {"LD_ATTN_Q64": "0", "LD_ATTN_SAFE": "1"}, {"LD_ATTN_Q64": "0", "LD_ATTN_NW": "8"}, {"LD_ATTN_Q64": "0", "LD_ATTN_NW": "8", "LD_ATTN_SAFE": "1"}, {"LD_ATTN_VARIANT": "9"}, {"LD_ATTN_VARIANT": "1"}, {"LD_ATTN_VARIANT": "4"},
                                  {"LD_ATTN_VARIANT": "8"}, {"LD_ATTN_VARIANT": "8", "LD_ATTN_SAFE": "1"}, {"LD_ATTN_VARIANT": "8", "LD_ATTN_NW": "8"},
-                                 {"LD_ATTN_MSUM": "0"}, {"LD_ATTN_MSUM": "0", "LD_ATTN_SAFE": "1"}])
+                                 {"LD_ATTN_Q64": "0", "LD_ATTN_MSUM": "0"}, {"LD_ATTN_Q64": "0", "LD_ATTN_MSUM": "0", "LD_ATTN_SAFE": "1"}])
 def test_attention_variants(cuda, env):
     assert _run(ATTN_SNIPPET, env) < 2e-2
 
