@@ -663,6 +663,7 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
   for (int it = 0; it < KV_MAXIT; ++it) {
     const int kk = wave * 4 + it * 16 + kq;
     kr[it] = (u32x4_t){0u, 0u, 0u, 0u}; vr[it] = (u32x4_t){0u, 0u, 0u, 0u};
+    if (it * 16 >= n) continue;
     if (kk < n) {
       const long off = (((long)b * Lmax + k_begin + kk) * H + h) * D + sub * 8;
       kr[it] = __builtin_nontemporal_load((const u32x4_t*)(kc + off));
@@ -701,11 +702,12 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
 #pragma unroll
   for (int it = 0; it < KV_MAXIT; ++it) {
     const int kk = wave * 4 + it * 16 + kq;
+    sreg[it] = -3.0e38f;
+    if (it * 16 >= n) continue;                       // workgroup-uniform: trips past this split's keys cost nothing
     float d = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { d = fmaf(qreg[2 * e], bf_lo(kr[it][e]), d); d = fmaf(qreg[2 * e + 1], bf_hi(kr[it][e]), d); }
     d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-    sreg[it] = -3.0e38f;
     if (kk < n) {
       sreg[it] = rbf(rbf(d) * inv_sqrt_d);
       lmax = fmaxf(lmax, sreg[it]);
@@ -722,6 +724,7 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
 #pragma unroll
   for (int it = 0; it < KV_MAXIT; ++it) {
     const int kk = wave * 4 + it * 16 + kq;
+    if (it * 16 >= n) continue;
     if (kk < n) {
       const float pk = __expf(sreg[it] - mx);
       if (sub == 0) lsum += pk;

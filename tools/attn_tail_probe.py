@@ -1,5 +1,5 @@
 """DiT attention launch at different head counts: how much the partial last round of workgroups costs (2 WGs per CU, 512 slots)."""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, ".")
 from landiff_amd import ops
 N = 17776; Npad = (N + 127) // 128 * 128
@@ -14,7 +14,8 @@ def run(B, H):
     for _ in range(10): ops.attn_fwd(q, k, vt, out, N, N, 0.125)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    wgs = B * H * (Npad // 128)
+    rows = 128 if os.environ.get("LD_ATTN_Q64") == "0" else 256
+    wgs = B * H * ((Npad + rows - 1) // rows)
     print(f"B*H={B*H:3d}: {wgs} workgroups = {wgs/512:6.3f} rounds  {ms:.3f} ms  {4*B*H*N*N*64/ms/1e9:.0f} TF  ({ms/(wgs/512)*1e3:.1f} us per round-equivalent)", flush=True)
 for rep in range(2):
-    for B, H in ((1, 55), (1, 59), (2, 30), (1, 63), (1, 64), (1, 70)): run(B, H)
+    for B, H in ((1, 51), (1, 55), (1, 58), (1, 59), (2, 30), (1, 62), (1, 64), (1, 66), (1, 73)): run(B, H)
