@@ -3,6 +3,8 @@
 //   NREAD ds_read_b128 (16 = each fragment read once; the attention kernel reads 28 per 64 MFMAs),
 //   NEXP  v_exp_f32    (the attention kernel issues 57 per 64 MFMAs),
 //   NCVT  v_cvt_pk_bf16_f32 (28 per 64 MFMAs in the attention kernel).
+// Caveat (measured): with one wave per SIMD the inline-asm additions make the loop issue-bound (2.39 GHz, below the power cap),
+// so the variants do not read as energy; the attention ablation (tools/attn_ablate.sh) replaced this probe.
 // No global-memory traffic.  Build: hipcc --offload-arch=gfx950 -O3 -o attn_energy attn_energy.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
