@@ -293,7 +293,7 @@ __device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&
           u32x4_t ow;
 #pragma unroll
           for (int e = 0; e < 4; ++e) ow[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-          *(u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0) = ow;
+          __builtin_nontemporal_store(ow, (u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0));
         }
       }
     };
@@ -422,7 +422,7 @@ __device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&ac
         if (gm < p.M) {
           const int b = gm >= bnd ? b0 + 1 : b0;
           const int n = gm - b * p.Ntok;
-          *(u32x4_t*)(dst + (((long)b * p.heads + h) * p.Npad + n) * 64 + sub * 8) = o;
+          __builtin_nontemporal_store(o, (u32x4_t*)(dst + (((long)b * p.heads + h) * p.Npad + n) * 64 + sub * 8));
         }
       }
     };
@@ -455,7 +455,7 @@ __device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&ac
       if (gm < p.M) {
         const int b = gm >= bnd ? b0 + 1 : b0;
         const int n = gm - b * p.Ntok;
-        *(u32x4_t*)(p.vt_out + (((long)b * p.heads + h) * 64 + d) * p.Npad + n) = val;
+        __builtin_nontemporal_store(val, (u32x4_t*)(p.vt_out + (((long)b * p.heads + h) * 64 + d) * p.Npad + n));
       }
     }
   }
