@@ -136,6 +136,24 @@ print("HASH", h.hexdigest())
 print("WORST", worst)
 """ % ROOT
 
+ATTN_HASH_SNIPPET = r"""
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from landiff_amd import ops
+torch.manual_seed(1)
+h = hashlib.sha256()
+# ragged last tile / exact tiles / a key count whose last HALF tile is empty / 6 tiles (the minimum), odd head counts
+for (B, H, N) in [(1, 3, 1122), (2, 1, 1408), (1, 2, 2065), (1, 1, 384), (1, 2, 777)]:
+    q = torch.randn(B, H, N, 64).cuda().bfloat16(); k = torch.randn(B, H, N, 64).cuda().bfloat16(); v = torch.randn(B, H, N, 64).cuda().bfloat16()
+    Npad = (N + 127) // 128 * 128
+    def pack(x):
+        o = torch.zeros(B, H, Npad, 64, device="cuda", dtype=x.dtype); o[:, :, :N] = x; return o
+    out = torch.zeros(B, N, H * 64, device="cuda", dtype=torch.bfloat16)
+    ops.attn_fwd(pack(q), pack(k), pack(v).transpose(2, 3).contiguous(), out, N, N, 0.125)
+    h.update(out.cpu().view(torch.int16).numpy().tobytes())
+print("HASH", h.hexdigest())
+""" % ROOT
+
 
 def _run(snippet, env):
     e = dict(os.environ); e.update(env)
@@ -163,6 +181,18 @@ def test_layernorm_modulate_forms(cuda, env):
     """The DiT's LayerNorm + modulate: the two-rows-per-wave pair kernel (default) and the general kernel (LD_LN_FAST=0)
     against a torch restatement -- at most one bf16 step apart (the kernels round where the reference's bf16 ops round)."""
     assert _run(LN_SNIPPET, env) < 2 ** -7
+
+
+def test_attention_wave_tiles_bit_identical(cuda):
+    """The 64-query-row wave tile (ld_attn_q64, default) and the 32-row one (LD_ATTN_Q64=0) do the same per-lane arithmetic
+    in the same order -- outputs equal bit for bit, whatever the tail of the key axis looks like."""
+    outs = []
+    for env in ({}, {"LD_ATTN_Q64": "0"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", ATTN_HASH_SNIPPET], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
+    assert outs[0] == outs[1]
 
 
 def test_groupnorm_apply_forms(cuda):
