@@ -26,38 +26,69 @@ METRIC = "end-to-end frames/sec, 49f 480x720 @50 steps"
 # (profiles/r02_attn_q64_pmc_hbm.txt): (2 x FETCH_SIZE [gfx950 correction, MI355X_MICROARCH.md HBM] + WRITE_SIZE) x 1024
 # = (2 * 489400 + 141700) KiB.  Reported only when the run is that kernel at that shape.
 ATTN_TRAFFIC = {"kernel": "ld_attn_q64_kernel", "bytes": (2 * 489400 + 141700) * 1024}
+MFMA_BF16_PEAK = 2500.0      # TFLOP/s, dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK = 8000.0            # GB/s
+VAE_TFLOP = 315.0            # per 49-frame video (58.8 + 5 x 51.3)
 
 
-def cpu_baseline(cfg, budget_s: float = 25.0):
-    """The oracle (CPU restatement, "port") timed on the host cores on a bounded sample of the same workload:
-    one DiT layer-call at the full shape (B=2, N=17776), one LLM decode step, one TiTok decoder layer and one VAE
-    3x3x3 conv at a reduced extent; extrapolated with the multipliers of BASELINE.md section 3."""
+def _median(fn, n=5):
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def cpu_baseline(cfg):
+    """The oracle (CPU restatement, "port") timed on the host cores, as BASELINE.md section 3 lays out:
+      (i)  BASELINE configs[0] end to end (random-init tiny DiT, 8 latent frames, 64x64 latent, 2 DDIM steps: AR decode ->
+           detokenize -> sampler -> chunked VAE decode -> uint8 frames), and
+      (ii) at full shapes one unit of each hot kernel -- one DiT layer-call (B=2, N=17 776), one LLM decode layer (median of 5),
+           one TiTok decoder layer, one level-0 VAE resblock at 480x720 (2 frames) -- extrapolated with the explicit multipliers
+           45 x 50, 24 x 1244, 12 and 315 TFLOP / (resblock TFLOP/s) to seconds per 49-frame video (`value`)."""
     import dataclasses
-    from landiff_amd.weights import dit_spec, init_state, llm_spec, tokenizer_spec
+    from landiff_amd.config import PipelineConfig, VAEConfig
+    from landiff_amd.weights import _res3d, dit_spec, init_pipeline_state, init_state, llm_spec, tokenizer_spec
     from oracle.dit import DiTOracle
     from oracle.llm import LLMOracle
+    from oracle.pipeline import PipelineOracle
     from oracle.tokenizer import DetokenizerOracle, rope3d_table, frame_ids
+    from oracle.vae import VAEDecoderOracle
     cores = min(os.cpu_count() or 1, 64)      # torch CPU ops stop scaling (and small ops regress) far below 256 threads
     torch.set_num_threads(cores)
     out = {}
     with torch.no_grad():
+        # (i) configs[0] end to end
+        c0 = PipelineConfig.config0().check()
+        st0 = init_pipeline_state(c0, seed=1234)
+        orc = PipelineOracle(c0, st0, torch.float32)
+        g = torch.Generator().manual_seed(42)
+        text = torch.randn(6, c0.llm.text_dim, generator=g)
+        ctx = torch.randn(1, c0.dit.text_len, c0.dit.text_dim, generator=g)
+        d0 = c0.dit
+        noise = torch.randn(1, d0.latent_frames, d0.in_channels, d0.latent_h, d0.latent_w, generator=g)
+        t0 = time.perf_counter()
+        tok = orc.tokens(text)
+        z = orc.latent(tok, ctx, noise=noise)
+        _, fr = orc.frames(z)
+        out["config0_s"] = time.perf_counter() - t0
+        out["config0_frames"] = int(fr.shape[0])
+        del orc, st0
+        # (ii) full-shape units
         d1 = dataclasses.replace(cfg.dit, layers_main=1, layers_control=1)
         orc = DiTOracle(init_state(dit_spec(d1, False), 1), d1, False, torch.float32)
         h = torch.randn(2, d1.seq_len, d1.hidden)
         emb = torch.randn(2, d1.time_embed_dim)
         t0 = time.perf_counter(); orc.layer(0, h, emb); out["dit_layer_s"] = time.perf_counter() - t0
-        l1 = dataclasses.replace(cfg.llm, num_layers=2)
+        del orc, h
+        l1 = dataclasses.replace(cfg.llm, num_layers=1)
         lo = LLMOracle(init_state(llm_spec(l1), 2), l1, torch.float32)
-        cache = [(torch.randn(2, 1200, l1.heads, l1.head_dim), torch.randn(2, 1200, l1.heads, l1.head_dim)) for _ in range(2)]
+        kv = (torch.randn(2, 1200, l1.heads, l1.head_dim), torch.randn(2, 1200, l1.heads, l1.head_dim))
         cos, sin = torch.ones(1, 1, l1.head_dim // 2), torch.zeros(1, 1, l1.head_dim // 2)
         x = torch.randn(2, 1, l1.hidden)
-        def llm_layers():
-            c2 = list(cache)
-            y = x
-            for i in range(2):
-                y = lo.block(i, y, c2, cos, sin)
-        llm_layers()                                     # warm-up (thread pool start-up, first-touch)
-        t0 = time.perf_counter(); llm_layers(); out["llm_layer_s"] = (time.perf_counter() - t0) / 2
+        llm_layer = lambda: lo.block(0, x, [kv], cos, sin)
+        llm_layer()                                      # warm-up (thread pool start-up, first touch)
+        out["llm_layer_s"] = _median(llm_layer, 5)
+        del lo
         t1 = dataclasses.replace(cfg.tok, layers=1)
         to = DetokenizerOracle(init_state(tokenizer_spec(t1), 3), {}, t1, cfg.ups, torch.float32)
         xt = torch.randn(1, t1.seq_len, t1.width)
@@ -65,19 +96,36 @@ def cpu_baseline(cfg, budget_s: float = 25.0):
         fid = torch.from_numpy(frame_ids(t1))
         mask = (fid[None, :] <= fid[:, None])[None, None]
         t0 = time.perf_counter(); to.titok_block(0, xt, c3[None], s3[None], mask); out["titok_layer_s"] = time.perf_counter() - t0
-        xc = torch.randn(1, 128, 4, 120, 180)
-        wc = torch.randn(128, 128, 3, 3, 3)
-        torch.nn.functional.conv3d(xc, wc, padding=(0, 1, 1))      # warm-up
-        t0 = time.perf_counter(); torch.nn.functional.conv3d(xc, wc, padding=(0, 1, 1)); dt = time.perf_counter() - t0
-        out["conv_tflops"] = 2 * 128 * 128 * 27 * 2 * 120 * 180 / dt / 1e12
+        del to, mask
+        vc = VAEConfig()
+        C, T, H, W = vc.ch, 2, 480, 720
+        p = "decoder.up.0.block.1."
+        vo = VAEDecoderOracle(init_state(_res3d(p, C, C, vc.z_channels), 4), vc, torch.float32)
+        xv = torch.randn(1, C, T, H, W)
+        zq = torch.randn(1, vc.z_channels, 1, 60, 90)
+        t0 = time.perf_counter(); vo.resblock(xv, zq, p, C, C, True); dt = time.perf_counter() - t0
+        out["vae_resblock_s"] = dt
+        out["vae_tflops"] = 2 * (2.0 * T * H * W * C * C * 27) / dt / 1e12
     d, l = cfg.dit, cfg.llm
     total = (out["dit_layer_s"] * (d.layers_main + d.layers_control) * cfg.sampler.num_steps
-             + out["llm_layer_s"] * l.num_layers * 1244 + out["titok_layer_s"] * cfg.tok.layers + 315.0 / out["conv_tflops"])
+             + out["llm_layer_s"] * l.num_layers * 1244 + out["titok_layer_s"] * cfg.tok.layers + VAE_TFLOP / out["vae_tflops"])
     frames = 4 * d.latent_frames - 3
     return {"value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": ("oracle fp32 on host cores: 1 DiT layer-call (B=2,N=17776) %.1fs, 1 LLM decode layer %.3fs, 1 TiTok layer %.1fs, "
-                       "conv3d %.2f TFLOP/s; extrapolated x(45x50), x(24x1244), x12, 315 TFLOP -> %.0f s/video"
-                       % (out["dit_layer_s"], out["llm_layer_s"], out["titok_layer_s"], out["conv_tflops"], total))}
+            "extrapolated_seconds_per_video": round(total, 1),
+            "config0_end_to_end": {"seconds": round(out["config0_s"], 2), "frames": out["config0_frames"],
+                                   "frames_per_s": round(out["config0_frames"] / out["config0_s"], 3),
+                                   "workload": "BASELINE configs[0]: random-init tiny DiT, 8 latent frames, 64x64 latent, 2 DDIM steps, whole pipeline"},
+            "sample": ("oracle fp32 on host cores: configs[0] end to end %.1fs; full shapes: 1 DiT layer-call (B=2,N=17776) %.1fs, 1 LLM decode "
+                       "layer %.4fs (median of 5), 1 TiTok layer %.1fs, 1 level-0 VAE resblock (2 frames 480x720) %.1fs = %.2f TFLOP/s; "
+                       "extrapolated x(45x50), x(24x1244), x12, 315 TFLOP -> %.0f s/video"
+                       % (out["config0_s"], out["dit_layer_s"], out["llm_layer_s"], out["titok_layer_s"], out["vae_resblock_s"],
+                          out["vae_tflops"], total))}
+
+
+def llm_step_bytes(c) -> float:
+    """Weight bytes one AR decode step must stream (bf16 blocks + the fp32 head), SURVEY 8d: 4.06 GB at the shipped config."""
+    per_layer = (3 * c.hidden * c.hidden + c.hidden * c.hidden + 3 * c.mlp * c.hidden) * 2
+    return c.num_layers * per_layer + c.vocab * c.hidden * 4
 
 
 def main():
@@ -111,6 +159,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N-GPU runs with "
                          "`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...`")
     import torch.distributed as dist
+    from landiff_amd.pipeline import gather_rank_reports, pin_rank_cores
+    my_cores = pin_rank_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     # LD_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1 takes the RCCL code path (init, barrier, all_gather,
@@ -156,6 +206,7 @@ def main():
         one_step()
     pipe.timings = {}
     pipe.dit.attn_events = []
+    pipe.dit.gemm_events = []
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -163,6 +214,7 @@ def main():
     for _ in range(args.steps):
         out = one_step()
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -172,24 +224,62 @@ def main():
         elapsed = float(tmax.item())
 
     n_frames = out[0].shape[1]
+    stage_s = {k: v / args.steps for k, v in pipe.timings.items()}
+    reports = gather_rank_reports({"rank": rank, "frames_per_s": round(n_frames * args.steps / local_elapsed, 4),
+                                   "stage_seconds": {k: round(v, 3) for k, v in stage_s.items()},
+                                   "cores": len(my_cores) if my_cores else None}, world if use_dist else 1)
     if rank == 0:
         d = cfg.dit
         ev = pipe.dit.attn_events
         attn_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
         flops = 4.0 * 2 * d.heads * d.seq_len * d.seq_len * d.head_dim      # algorithmic FLOPs of one launch
         achieved = flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
-        peak = 2500.0
+        peak = MFMA_BF16_PEAK
         from landiff_amd import _lib
         kname = (_lib.load().ld_attn_last_kernel() or b"").decode()      # what the launcher actually ran (shape + LD_ATTN_* knobs)
         # the PMC traffic figure was collected on the default kernel at the headline shape only (profiles/, see ATTN_TRAFFIC)
         headline = (not args.tiny and not stream and not args.fp8_gemm and kname == ATTN_TRAFFIC["kernel"]
                     and not any(os.environ.get(k) for k in ("LD_ATTN_NW", "LD_ATTN_SAFE", "LD_ATTN_VARIANT", "LD_ATTN_MSUM", "LD_ATTN_Q64")))
+        attn_roof = {"kernel": "%s (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (kname, d.heads, d.seq_len),
+                     "bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4),
+                     "traffic": ATTN_TRAFFIC["bytes"] if headline else None, "launches": len(ev),
+                     "avg_launch_ms": round(attn_ms, 4)}
+        # ---- per-stage achieved vs peak (rank 0) ----------------------------------------------------
+        stages = {"dit_attention": {k: attn_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
+        stages["dit_attention"]["seconds_per_step"] = round(attn_ms * 1e-3 * len(ev) / args.steps, 3)
+        gev = pipe.dit.gemm_events
+        if gev:
+            g_s = sum(a.elapsed_time(b) for a, b, _ in gev) * 1e-3
+            g_fl = sum(f for _, _, f in gev)
+            g_ach = g_fl / g_s / 1e12
+            g_peak = peak if not args.fp8_gemm else 2 * peak
+            stages["dit_gemm"] = {"bound": "mfma", "achieved": round(g_ach, 1), "peak": g_peak, "unit": "TFLOP/s", "frac": round(g_ach / g_peak, 4),
+                                  "seconds_per_step": round(g_s / args.steps, 3), "launches": len(gev),
+                                  "what": "HIP events around every qkv / dense / 4h / 4h->h Linear and control zero-linear of the DiT loop "
+                                          "(2 M N K each; 3.145 TFLOP per layer-call + 0.262 per control layer), tail launches included"
+                                          + ("; e4m3 operands: priced against the dense fp8 peak" if args.fp8_gemm else "")}
+        if "llm" in stage_s and not stream and P == 1 and not args.tiny:
+            steps_llm = 1244
+            gbs = llm_step_bytes(cfg.llm) * steps_llm / stage_s["llm"] / 1e9
+            stages["llm_decode"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(gbs / HBM_PEAK, 4),
+                                    "seconds_per_step": round(stage_s["llm"], 3),
+                                    "what": "%d decode steps x %.3f GB of weights (bf16 blocks + fp32 head) / the llm stage's wall time (prefill included)"
+                                            % (steps_llm, llm_step_bytes(cfg.llm) / 1e9)}
+        if "vae" in stage_s and not stream and P == 1 and not args.tiny:
+            tf = VAE_TFLOP / stage_s["vae"]
+            stages["vae_decode"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                                    "seconds_per_step": round(stage_s["vae"], 3),
+                                    "what": "315 TFLOP of causal 3D / 2D convolutions per 49-frame video / the vae stage's wall time (norm, upsample and uint8 passes included)"}
+        serving = P > 1
         res = {
-            "metric": METRIC, "value": world * n_frames * args.steps / elapsed, "unit": "frames/s",
+            "metric": METRIC if not serving else METRIC + " [SERVING MODE: %d prompts per GPU and step, AR decode overlapped -- not the BASELINE configuration]" % P,
+            "value": world * n_frames * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if not args.fp8_gemm else f"bf16 with fp8-e4m3 ({args.fp8_gemm}) DiT linears (configs[4], not the headline precision)",
             "data": "synthetic",
+            "serving_mode": serving,
             "config": {"workload": ("tiny random-init plumbing config" if args.tiny else
                                     "LanDiff 5B full pipeline, single prompt per GPU, 49f 480x720, 50 sampler steps "
                                     "(VPSDE DPM-Solver++(2M), DynamicCFG), bf16, random-init weights at true shapes")
@@ -197,18 +287,20 @@ def main():
                                       f"chunk, {n_frames} frames" if stream else "")
                                    + (f"; fp8 e4m3 MFMA ({args.fp8_gemm} scaling) for the DiT qkv/dense/4h/4h->h linears" if args.fp8_gemm else "")
                                    + (f"; SERVING MODE, not the BASELINE configuration: {P} prompts per GPU and step, AR decode of prompt "
-                                      f"i+1 overlapped with the DiT loop of prompt i (generate_many)" if P > 1 else ""),
+                                      f"i+1 overlapped with the DiT loop of prompt i (generate_many)" if serving else ""),
                        "frames": n_frames, "height": 8 * d.latent_h, "width": 8 * d.latent_w,
                        "sampler_steps": cfg.sampler.num_steps, "llm_steps": (1244 if not stream else None) if not args.tiny else None,
                        "prompts_per_step": P,
                        "parallelism": f"dp{world} over prompts, RCCL all_gather of uint8 frames only"},
-            "stage_seconds_rank0": {k: round(v / args.steps, 3) for k, v in pipe.timings.items()},
-            "roofline": {"kernel": "%s (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (kname, d.heads, d.seq_len),
-                         "bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4),
-                         "traffic": ATTN_TRAFFIC["bytes"] if headline else None, "launches": len(ev),
-                         "avg_launch_ms": round(attn_ms, 4)},
+            "roofline": attn_roof,
+            "roofline_stages": stages,
         }
+        if not serving:            # generate_many records no per-stage wall times (its stages overlap)
+            res["stage_seconds_rank0"] = {k: round(v, 3) for k, v in stage_s.items()}
+        if world > 1 or use_dist:
+            fps = [r["frames_per_s"] for r in reports]
+            res["per_rank"] = {"frames_per_s_min": min(fps), "frames_per_s_max": max(fps), "frames_per_s": fps,
+                               "stage_seconds": [r["stage_seconds"] for r in reports], "cores_per_rank": [r["cores"] for r in reports]}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(PipelineConfig.full())
         print(json.dumps(res))

@@ -18,7 +18,10 @@
 extern "C" {
 #endif
 
-#define LD_ABI_VERSION 1
+/* Bumped whenever a signature changes or an entry point is added / removed (2: ld_groupnorm_stats took its `partials`
+ * argument, ld_gemm_qkv_heads / ld_llm_sample_advance / ld_groupnorm_stats_blocks / ld_attn_last_kernel were added).  A caller
+ * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does). */
+#define LD_ABI_VERSION 2
 
 int ld_version(void);
 const char* ld_last_error(void);

@@ -51,7 +51,11 @@ def main():
     import os
 
     args = parse_args()
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1:      # one process per GPU (prompt-level data parallelism): own core slice per rank
+        from landiff_amd.pipeline import pin_rank_cores
+        pin_rank_cores(local_rank, int(os.environ["LOCAL_WORLD_SIZE"]))
+    torch.cuda.set_device(local_rank)
     infer_diffusion(args, llm_infer(args))
 
 

@@ -15,6 +15,12 @@ def set_seed_for_single_process(seed: int):
     np.random.seed(seed)
 
 
+def stable_hash(key: str) -> int:
+    """landiff/utils.py:317-324: first 20 hex digits of sha256(key) (Python's hash() is salted per process)."""
+    import hashlib
+    return int(hashlib.sha256(key.encode()).hexdigest()[:20], 16)
+
+
 def cthw_to_numpy_images(video: torch.Tensor) -> np.ndarray:
     """landiff/utils.py:327-331: [C,T,H,W] in [0,1] -> uint8 [T,H,W,C] by truncation."""
     assert video.dim() == 4, "video must be 4D tensor"

@@ -43,6 +43,7 @@ class LlmLayer(Structure):
 
 
 _lib = None
+ABI_VERSION = 2          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
 
 I64 = c_int64
 I32 = c_int32
@@ -104,6 +105,10 @@ def load():
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
     lib = ctypes.CDLL(LIB_PATH)
+    lib.ld_version.restype = c_int
+    if lib.ld_version() != ABI_VERSION:
+        raise LandiffHipError(f"{LIB_PATH} reports ABI version {lib.ld_version()}, this binding was written for {ABI_VERSION}: "
+                              "rebuild the library (__graft_entry__.build()) -- the argument lists would not match")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -30,6 +30,10 @@ class LLMConfig:
     pframe_len: int = 74
     segment_length: int = 13
     segment_stride: int = 13
+    # TextCond's encoder (llm_cfg.py:60-61 -> FlanT5XXL(model_path="google/flan-t5-xxl"), text_encoder.py:137-146): an HF hub
+    # name or a local directory with the T5 encoder checkpoint + tokenizer; max_cond_tokens_num=512 (llm_cfg.py:62)
+    text_encoder_path: str = "google/flan-t5-xxl"
+    max_cond_tokens: int = 512
 
     @property
     def head_dim(self) -> int:
@@ -60,6 +64,12 @@ class LLMConfig:
         return LLMConfig(num_layers=2, hidden=256, heads=2, mlp=512, visual_vocab=64, text_dim=128,
                          freq_dim=64, micro_hidden=64, iframe_len=6, pframe_len=3, segment_length=3,
                          segment_stride=3)
+
+    @staticmethod
+    def config0() -> "LLMConfig":
+        """Goes with DiTConfig.config0() / TokenizerConfig.config0(): 8 semantic frames, 64 I tokens + 7 x 16 P tokens."""
+        return LLMConfig(num_layers=2, hidden=256, heads=2, mlp=512, visual_vocab=64, text_dim=128, freq_dim=64,
+                         micro_hidden=64, iframe_len=64, pframe_len=16, segment_length=8, segment_stride=8)
 
 
 @dataclass(frozen=True)
@@ -101,6 +111,13 @@ class TokenizerConfig:
                                pframe_tokens=3, num_latent_tokens=12, codebook_size=64, codebook_dim=16,
                                token_size=128, out_channels=128)
 
+    @staticmethod
+    def config0() -> "TokenizerConfig":
+        """BASELINE.json configs[0]: 8 frames on a 32x32 semantic grid (= half the 64x64 latent), 64 + 7 x 16 latent tokens."""
+        return TokenizerConfig(width=128, layers=2, heads=2, grid_h=32, grid_w=32, temporal=8, pframe_tokens=16,
+                               num_latent_tokens=64 + 7 * 16, codebook_size=64, codebook_dim=16, token_size=128,
+                               out_channels=128)
+
 
 @dataclass(frozen=True)
 class UpsamplerConfig:
@@ -134,6 +151,9 @@ class DiTConfig:
     latent_h: int = 60
     latent_w: int = 90
     latent_frames: int = 13
+    # frames covered by the checkpoint's position table, (num_frames - 1) // time_compressed_rate + 1 (dit_video_concat.py:
+    # 200-231: the forward slices the first text_len + seq_length rows); 0 = latent_frames
+    pos_frames: int = 0
     text_len: int = 226
     text_dim: int = 4096
     block_ln_eps: float = 1e-5         # sat layernorm_epsilon default
@@ -153,6 +173,8 @@ class DiTConfig:
     def n_img(self): return self.latent_frames * self.grid_h * self.grid_w
     @property
     def seq_len(self): return self.text_len + self.n_img
+    @property
+    def pos_rows(self): return self.text_len + (self.pos_frames or self.latent_frames) * self.grid_h * self.grid_w
 
     @staticmethod
     def tiny() -> "DiTConfig":
@@ -210,15 +232,156 @@ class PipelineConfig:
         return PipelineConfig()
 
     @staticmethod
+    def config0(num_steps: int = 2) -> "PipelineConfig":
+        """BASELINE.json configs[0]: random-init tiny DiT, 8 latent frames, 64x64 latent, 2 DDIM steps (plumbing run of the
+        landiff.infer_video entry point)."""
+        return PipelineConfig(LLMConfig.config0(), TokenizerConfig.config0(), UpsamplerConfig.tiny(), DiTConfig.config0(),
+                              VAEConfig.tiny(), SamplerConfig(num_steps=num_steps, sampler="ddim"))
+
+    @staticmethod
     def tiny(num_steps: int = 3) -> "PipelineConfig":
         return PipelineConfig(LLMConfig.tiny(), TokenizerConfig.tiny(), UpsamplerConfig.tiny(), DiTConfig.tiny(),
                               VAEConfig.tiny(), SamplerConfig(num_steps=num_steps))
 
-    def check(self):
-        assert self.tok.temporal == self.dit.latent_frames
-        assert self.llm.iframe_len == self.tok.iframe_tokens and self.llm.pframe_len == self.tok.pframe_tokens
-        assert self.llm.visual_vocab == self.tok.codebook_size
+    def check_diffusion(self):
+        """Consistency of the diffusion-side parts (tokenizer decoder / upsampler / DiT / VAE)."""
+        assert self.tok.temporal == self.dit.latent_frames, "sampling_num_frames must equal the tokenizer's temporal_size"
         assert self.dit.latent_h == 2 * self.tok.grid_h and self.dit.latent_w == 2 * self.tok.grid_w
         assert self.ups.z_channels == self.tok.out_channels and self.ups.target_dim == self.dit.in_channels
         assert self.vae.z_channels == self.dit.in_channels
         return self
+
+    def check(self):
+        self.check_diffusion()
+        assert self.llm.iframe_len == self.tok.iframe_tokens and self.llm.pframe_len == self.tok.pframe_tokens
+        assert self.llm.visual_vocab == self.tok.codebook_size
+        return self
+
+
+def build_tokenizer_config0() -> TokenizerConfig:
+    """`config_str` target for a configs[0] model YAML (the shipped YAML names landiff.tokenizer.tokenizer_cfg.build_tokenizer)."""
+    return TokenizerConfig.config0()
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's two YAML files (landiff/diffusion/configs/*.yaml) -> the dataclasses above
+# ------------------------------------------------------------------------------------------------
+_SAMPLERS = {"VPSDEDPMPP2MSampler": "vpsde_dpmpp2m", "VideoDDIMSampler": "ddim"}
+_GUIDERS = ("DynamicCFG",)
+
+
+@dataclass(frozen=True)
+class DiffusionInferConfig:
+    """Everything CogModelInferWrapper reads from `model_cfg_path` + `infer_cfg_path` (dif_infer.py:274-287: "--base
+    {model_cfg_path} {infer_cfg_path} --load {ckpt_path}", merged by arguments.py:302-329)."""
+    dit: DiTConfig
+    tok: TokenizerConfig
+    ups: UpsamplerConfig
+    vae: VAEConfig
+    sampler: SamplerConfig
+    t5_dir: str                 # conditioner_config ... FrozenT5Embedder.params.model_dir
+    tokenizer_ckpt: str         # VideoVQWrap.params.ckpt_path
+    vae_ckpt: str               # first_stage_config.params.ckpt_path
+    base_dit_ckpt: str          # model.pretrain_diffusion_model_ckpt_path
+    image_size: tuple           # args.sampling_image_size
+    fps: int                    # args.sampling_fps
+    bf16: bool
+    force_inference: bool       # non-strict checkpoint load (infer_cfgs/2b.yaml:13)
+
+    def pipeline(self, llm: LLMConfig | None = None) -> "PipelineConfig":
+        return PipelineConfig(llm or LLMConfig(), self.tok, self.ups, self.dit, self.vae, self.sampler)
+
+
+def _cls(target: str) -> str:
+    return target.rsplit(".", 1)[-1]
+
+
+def load_diffusion_config(model_cfg_path: str, infer_cfg_path: str) -> DiffusionInferConfig:
+    """Reads the reference's model YAML (cogvideox_2b_control_theia_interpolate_video_vq.yaml :1-243) and inference YAML
+    (infer_cfgs/2b.yaml :1-13) with PyYAML.  Only the `target:` classes of the shipped configuration are accepted; every
+    shape of the diffusion side of the path comes from these files, nothing is assumed."""
+    import importlib
+    import yaml
+    with open(model_cfg_path) as f:
+        m = yaml.safe_load(f)["model"]
+    with open(infer_cfg_path) as f:
+        a = yaml.safe_load(f)["args"]
+    net, ctl = m["network_config"], m["control_network_config"]
+    assert _cls(net["target"]) == "DiffusionTransformer" and _cls(ctl["target"]) == "ControlDiffusionTransformer", \
+        "network_config / control_network_config must be the DiffusionTransformer / ControlDiffusionTransformer pair"
+    n, c = net["params"], ctl["params"]
+    for k in ("time_embed_dim", "hidden_size", "num_attention_heads", "patch_size", "in_channels", "out_channels",
+              "latent_width", "latent_height", "num_frames", "time_compressed_rate"):
+        assert n[k] == c[k], f"main and control DiT disagree on {k}: {n[k]} vs {c[k]}"
+    assert n["transformer_args"].get("layernorm_order", "pre") == "pre" and not n["transformer_args"].get("is_decoder", False)
+    nm, cm = n["modules"], c["modules"]
+    assert _cls(nm["pos_embed_config"]["target"]) == "Basic3DPositionEmbeddingMixin", "only the additive 3D sin-cos position embedding is built"
+    assert _cls(nm["adaln_layer_config"]["target"]) == "ControlAdaLNMixin" and _cls(cm["adaln_layer_config"]["target"]) == "ControlOutAdaLNMixin"
+    assert nm["adaln_layer_config"]["params"].get("qk_ln", True) and cm["adaln_layer_config"]["params"].get("qk_ln", True), "qk_ln: True expected"
+    assert cm["adaln_layer_config"]["params"].get("use_zero_linears", False), "use_zero_linears: true expected"
+    assert not c.get("use_semantic_injection_adaln", False) and not nm["adaln_layer_config"]["params"].get("use_semantic_injection_adaln", False)
+    control_layers = nm["adaln_layer_config"]["params"].get("control_layers", c["num_layers"])
+    assert control_layers == c["num_layers"], "control_layers must equal the control DiT's num_layers"
+    pos = nm["pos_embed_config"]["params"]
+    assert pos == cm["pos_embed_config"]["params"], "main and control position embeddings differ"
+    latent_frames = int(a["sampling_num_frames"])
+    H, W = a["sampling_image_size"]
+    assert H % 8 == 0 and W % 8 == 0 and H // 8 == n["latent_height"] and W // 8 == n["latent_width"], \
+        "sampling_image_size must be 8x the DiT's latent_height / latent_width (the position table is built for that grid)"
+    # the position table covers (num_frames - 1) // time_compressed_rate + 1 latent frames (dit_video_concat.py:200-226)
+    table_frames = (n["num_frames"] - 1) // n["time_compressed_rate"] + 1
+    assert latent_frames <= table_frames, f"sampling_num_frames {latent_frames} exceeds the position table ({table_frames} latent frames)"
+    assert a["latent_channels"] == n["in_channels"]
+    dit = DiTConfig(hidden=n["hidden_size"], heads=n["num_attention_heads"], layers_main=n["num_layers"], layers_control=c["num_layers"],
+                    time_embed_dim=n["time_embed_dim"], patch=n["patch_size"], in_channels=n["in_channels"], out_channels=n["out_channels"],
+                    latent_h=n["latent_height"], latent_w=n["latent_width"], latent_frames=latent_frames,
+                    pos_frames=table_frames, text_len=pos["text_length"],
+                    text_dim=nm["patch_embed_config"]["params"]["text_hidden_size"],
+                    height_interpolation=float(pos.get("height_interpolation", 1.0)),
+                    width_interpolation=float(pos.get("width_interpolation", 1.0)),
+                    time_interpolation=float(pos.get("time_interpolation", 1.0)))
+    # semantic conditioner: tokenizer (a config function named by config_str, as VQWarp.__init__ imports it) + conv upsampler
+    sc = cm["semantic_condition_config"]["params"]
+    assert sc.get("feature_type", "video_theia_interpolate") == "video_theia_interpolate"
+    vq = sc["semantic_model_config"]["params"]
+    mod, fn = vq["config_str"].rsplit(".", 1)
+    tok = getattr(importlib.import_module(mod), fn)()
+    assert isinstance(tok, TokenizerConfig), f"{vq['config_str']}() must return a landiff_amd.config.TokenizerConfig"
+    up = sc["upsample_model_config"]["params"]
+    assert up.get("upsample_type", "pixelshuffle") == "pixelshuffle" and not up.get("attn_resolutions") and not up.get("use_mid_attention", False)
+    ups = UpsamplerConfig(z_channels=up["z_channels"], ch=up["ch"], ch_mult=tuple(up["ch_mult"]), num_res_blocks=up["num_res_blocks"],
+                          out_ch=up["out_ch"], target_dim=sc["target_dim"])
+    assert sc["out_dim"] == up["out_ch"]
+    fs = m["first_stage_config"]["params"]
+    dec = fs["decoder_config"]["params"]
+    assert _cls(fs["decoder_config"]["target"]) == "ContextParallelDecoder3D" and not dec.get("gather_norm", False) and not dec.get("attn_resolutions")
+    vae = VAEConfig(ch=dec["ch"], ch_mult=tuple(dec["ch_mult"]), num_res_blocks=dec["num_res_blocks"], z_channels=dec["z_channels"],
+                    out_ch=dec["out_ch"], temporal_compress_times=n["time_compressed_rate"], scale_factor=float(m["scale_factor"]))
+    # sampler stack
+    smp = m["sampler_config"]
+    kind = _cls(smp["target"])
+    assert kind in _SAMPLERS, f"sampler {kind}: only {sorted(_SAMPLERS)} are built"
+    sp = smp["params"]
+    assert sp.get("fixed_frames", 0) in (0, None), "fixed_frames is the streaming primitive (generate_stream), not a config-file switch here"
+    den = m["denoiser_config"]["params"]
+    assert _cls(m["denoiser_config"]["target"]) == "DiscreteDenoiser" and _cls(den["scaling_config"]["target"]) == "VideoScaling"
+    disc = sp["discretization_config"]
+    assert _cls(disc["target"]) == "ZeroSNRDDPMDiscretization" and _cls(den["discretization_config"]["target"]) == "ZeroSNRDDPMDiscretization"
+    shift = float(disc.get("params", {}).get("shift_scale", 1.0))
+    assert shift == float(den["discretization_config"].get("params", {}).get("shift_scale", 1.0)), "sampler and denoiser discretizations differ"
+    gd = sp["guider_config"]
+    assert _cls(gd["target"]) in _GUIDERS, "guider: DynamicCFG expected"
+    gp = gd["params"]
+    assert gp.get("num_steps", sp["num_steps"]) == sp["num_steps"]
+    sampler = SamplerConfig(num_steps=int(sp["num_steps"]), cfg_scale=float(gp["scale"]), cfg_exp=float(gp["exp"]), shift_scale=shift,
+                            num_idx=int(den["num_idx"]), sampler=_SAMPLERS[kind])
+    emb = m["conditioner_config"]["params"]["emb_models"]
+    assert len(emb) == 1 and _cls(emb[0]["target"]) == "FrozenT5Embedder" and emb[0]["input_key"] == "txt"
+    assert emb[0]["params"]["max_length"] == pos["text_length"], "T5 max_length must equal the DiT's text_length"
+    cfg = DiffusionInferConfig(dit=dit, tok=tok, ups=ups, vae=vae, sampler=sampler, t5_dir=emb[0]["params"]["model_dir"],
+                               tokenizer_ckpt=vq.get("ckpt_path") or "", vae_ckpt=fs["ckpt_path"],
+                               base_dit_ckpt=m["pretrain_diffusion_model_ckpt_path"], image_size=(int(H), int(W)),
+                               fps=int(a.get("sampling_fps", 8)), bf16=bool(a.get("bf16", True)),
+                               force_inference=bool(a.get("force_inference", False)))
+    cfg.pipeline().check_diffusion()
+    return cfg

@@ -199,10 +199,20 @@ class Detokenizer:
         return h.view(F, H, W, uc.out_ch)
 
     @torch.no_grad()
+    def semantic_condition_from_features(self, features: torch.Tensor) -> torch.Tensor:
+        """SemanticCond.forward(semantic_feature_before_upsample=...) (condition.py:85-110,112-137): detokenizer features
+        [1, T, C, h, w] (or [T, C, h, w]) given by the caller -> upsampler -> conv_out -> [T, target_dim, 2h, 2w] bf16."""
+        f = features.reshape(-1, *features.shape[-3:]).to(self.dev, BF).permute(0, 2, 3, 1).contiguous()     # channels-last
+        return self._condition_from_cl(f)
+
+    @torch.no_grad()
     def semantic_condition(self, tokens: torch.Tensor) -> torch.Tensor:
         """-> [T, target_dim, 2h, 2w] bf16 (the tensor the control DiT adds to its input latent)."""
+        return self._condition_from_cl(self.index_to_feature(tokens))
+
+    def _condition_from_cl(self, feats_cl: torch.Tensor) -> torch.Tensor:
         uc = self.uc
-        f = self.upsample(self.index_to_feature(tokens))
+        f = self.upsample(feats_cl)
         F, H, W, C = f.shape
         out = self._conv3x3(self._pad(f.reshape(-1, C), F, H, W, C), "conv_out", F, H, W)     # [F*H*W, target_dim]
         return out.view(F, H, W, uc.target_dim).permute(0, 3, 1, 2).contiguous()

@@ -34,7 +34,7 @@ class _Branch:
         g = lambda k: _dev(sd[k], device)
         self.te0_w, self.te0_b = g("time_embed.0.weight"), g("time_embed.0.bias")
         self.te2_w, self.te2_b = g("time_embed.2.weight"), g("time_embed.2.bias")
-        self.pos = g("mixins.pos_embed.pos_embedding")[0]                       # [seq, d]
+        self.pos = g("mixins.pos_embed.pos_embedding")[0][: cfg.seq_len].contiguous()    # [seq, d]: the first text_len + seq_length rows (:227-231)
         self.patch_w = g("mixins.patch_embed.proj.weight").reshape(d, -1).contiguous()   # [d, C*p*p]
         self.patch_b = g("mixins.patch_embed.proj.bias")
         self.text_w, self.text_b = g("mixins.patch_embed.text_proj.weight"), g("mixins.patch_embed.text_proj.bias")
@@ -128,6 +128,7 @@ class ControlDiTRunner:
         self.fuse_qkv = (not self.fp8 and self.N % 8 == 0 and self.N >= 256 and c.head_dim == 64
                          and os.environ.get("LD_DIT_FUSE_QKV", "1") != "0")
         self.attn_events = None                 # bench.py: list of (start, end) HIP events around every attention launch
+        self.gemm_events = None                 # bench.py: list of (start, end, flops) around the large linears (qkv, dense, 4h, 4h->h, zero)
 
     # ---- per-video setup -------------------------------------------------------------------
     def set_condition(self, context: torch.Tensor, semantic_feature: torch.Tensor):
@@ -170,10 +171,22 @@ class ControlDiTRunner:
             ops.gemm(self.patches, br.patch_w, out=hv[b, c.text_len:], bias=br.patch_b, add2=br.pos[c.text_len:])
             hv[b, :c.text_len].copy_(txt[b])
 
+    def _timed(self, flops: float, fn, *a, **kw):
+        """fn(*a, **kw), bracketed by HIP events on the current stream when bench.py asked for GEMM timings."""
+        if self.gemm_events is None:
+            return fn(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **kw)
+        e1.record()
+        self.gemm_events.append((e0, e1, flops))
+        return r
+
     def _linear(self, x: torch.Tensor, lw: dict, name: str, out: torch.Tensor, **epi):
         """One of the four large nn.Linear sites of a block: bf16 MFMA GEMM, or (fp8_gemm) quantise + e4m3 GEMM."""
         if not self.fp8:
-            return ops.gemm(x, lw[name + "_w"], out=out, bias=lw[name + "_b"], **epi)
+            w = lw[name + "_w"]
+            return self._timed(2.0 * x.shape[0] * w.shape[0] * w.shape[1], ops.gemm, x, w, out=out, bias=lw[name + "_b"], **epi)
         K = x.shape[1]
         a8 = self.a8.view(-1)[: x.shape[0] * K].view(x.shape[0], K)
         ops.quantize_fp8(x, a8, self.sa)
@@ -223,8 +236,8 @@ class ControlDiTRunner:
                       shift_txt=6 * d, scale_txt=7 * d, **mod)
         if self.fuse_qkv:
             # qkv Linear + head split + QK-LayerNorm + V transpose in one launch (q / k / vt padding rows stay zero from allocation)
-            ops.gemm_qkv_heads(self.ln, lw["qkv_w"], lw["qkv_b"], self.q, self.k, self.vt, self.B, N, c.heads, self.Npad,
-                               lw["qln"], eps=c.qk_ln_eps)
+            self._timed(2.0 * self.M * 3 * d * d, ops.gemm_qkv_heads, self.ln, lw["qkv_w"], lw["qkv_b"], self.q, self.k, self.vt,
+                        self.B, N, c.heads, self.Npad, lw["qln"], eps=c.qk_ln_eps)
         else:
             self._linear(self.ln, lw, "qkv", self.qkv)
             ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
@@ -246,7 +259,7 @@ class ControlDiTRunner:
         h_in = self.hc
         for i in range(c.layers_control):
             self._layer(self.ctrl, i, h_in, self.hc)
-            ops.gemm(self.hc, self.ctrl.layers[i]["zero_w"], out=self.ctrl_out[i])
+            self._timed(2.0 * self.M * c.hidden * c.hidden, ops.gemm, self.hc, self.ctrl.layers[i]["zero_w"], out=self.ctrl_out[i])
             h_in = self.ctrl_out[i]
         # main branch
         self._time_emb(self.main, timestep)

@@ -120,22 +120,30 @@ class LanDiffPipeline:
         for inp in inputs:
             assert inp.seed, "generate_many needs a non-zero seed per prompt (a zero seed would draw from the shared default generator)"
         side = torch.cuda.Stream(device=self.dev, priority=-1)
+        main = torch.cuda.current_stream(self.dev)
 
         def decode_tokens(inp):
             torch.cuda.set_device(self.dev)
             with torch.cuda.stream(side):
                 tok = self.llm.sample(inp.llm_text_emb, motion_score=inp.motion_score, num_frames=self.cfg.llm.segment_length,
                                       guidance_scale=inp.cfg, temperature=1.0, seed=inp.seed).clone()   # (the runner reuses its token buffer)
+                tok.record_stream(main)               # allocated on the side stream, read on the main one: keep the block until that read is done
                 side.synchronize()                    # the tokens are complete before any other stream reads them
             return tok
 
+        def submit(pool, inp):
+            # The decode reads the prompt embedding (and the LLM's buffers) on the side stream: order it after everything the
+            # caller has queued on the current stream so far -- e.g. a text encoder that has just produced inp.llm_text_emb.
+            side.wait_stream(main)
+            return pool.submit(decode_tokens, inp)
+
         out = []
         with ThreadPoolExecutor(max_workers=1) as pool:
-            fut = pool.submit(decode_tokens, inputs[0])
+            fut = submit(pool, inputs[0])
             for i, inp in enumerate(inputs):
                 tokens = fut.result()
                 if i + 1 < len(inputs):
-                    fut = pool.submit(decode_tokens, inputs[i + 1])
+                    fut = submit(pool, inputs[i + 1])
                 d = self.cfg.dit
                 torch.manual_seed(inp.seed)
                 torch.cuda.manual_seed(inp.seed)
@@ -211,6 +219,7 @@ class LanDiffPipeline:
                     decode_state["error"] = e
                     for ev in queued:
                         ev.set()
+            side.wait_stream(torch.cuda.current_stream(self.dev))     # the decode reads inp.llm_text_emb: after whatever produced it
             decode_thread = threading.Thread(target=run_decode)
             decode_thread.start()
             def seg_tokens(sidx):
@@ -240,9 +249,15 @@ class LanDiffPipeline:
             return torch.cat(parts, dim=0).contiguous()
         outs, vids, prev = [], [], None
         for c in range(n_chunks):
+            t_w = time.perf_counter()
+            d0 = self.timings.get("detokenize", 0.0)
+            sem = sem_window(c * new, c * new + T)             # (may wait on the overlapped decode; detokenize is timed inside)
+            wait = time.perf_counter() - t_w - (self.timings.get("detokenize", 0.0) - d0)
+            if decode_thread is not None:
+                self.timings["segment_wait"] = self.timings.get("segment_wait", 0.0) + wait
             t0 = time.perf_counter()
             torch.manual_seed(inp.seed + c); torch.cuda.manual_seed(inp.seed + c)
-            self.dit.set_condition(inp.dit_context, sem_window(c * new, c * new + T))
+            self.dit.set_condition(inp.dit_context, sem)
             noise = noises[c].to(self.dev) if noises is not None else torch.randn(
                 1, T, d.in_channels, d.latent_h, d.latent_w, device=self.dev, dtype=torch.float32)
             if c == 0:
@@ -327,4 +342,42 @@ def gather_prompt_frames(local_frames: list, n_prompts: int, rank: int, world: i
     for r, g in enumerate(gathered):
         for i, pid in enumerate(shard_prompts(n_prompts, r if len(gathered) > 1 else rank, world)):
             out[pid] = g[i]
+    return out
+
+
+def rank_core_slice(local_rank: int, local_world: int, cores: list | None = None) -> list:
+    """The host cores of one rank: the cores this process may run on (its cpuset), cut into `local_world` contiguous, disjoint
+    slices.  One process per GPU each runs a latency-sensitive enqueue loop (the AR decode queues ~150 launches per 1.3 ms
+    step from one thread, 0.54 ms of host time per step): eight of them left to the scheduler migrate across cores and share
+    caches; a fixed slice per rank keeps every rank's enqueue thread, its helper thread (generate_many / generate_stream) and
+    its RCCL proxy thread on cores of their own."""
+    if cores is None:
+        cores = sorted(os.sched_getaffinity(0))
+    n = len(cores)
+    if local_world <= 1 or n < local_world:
+        return list(cores)
+    per = n // local_world
+    return list(cores[local_rank * per:(local_rank + 1) * per])
+
+
+def pin_rank_cores(local_rank: int, local_world: int) -> list:
+    """Applies rank_core_slice to this process (all threads created afterwards inherit it) and sizes torch's intra-op pool to
+    it.  Returns the slice.  LD_NO_PIN=1 leaves the affinity alone."""
+    if os.environ.get("LD_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    mine = rank_core_slice(local_rank, local_world)
+    if mine:
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), torch.get_num_threads())))
+    return mine
+
+
+def gather_rank_reports(report: dict, world: int) -> list:
+    """Every rank's small report dict (stage seconds, frames/s, ...) on every rank, in rank order: how an N > 1 bench line
+    carries per-rank numbers next to the max-over-ranks time.  One all_gather_object outside the timed region."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or world == 1:
+        return [report]
+    out = [None] * world
+    dist.all_gather_object(out, report)
     return out

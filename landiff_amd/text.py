@@ -28,10 +28,11 @@ def _load(name_or_dir: str, device_str: str):
 
 
 @torch.no_grad()
-def encode_flan_t5(prompts: list[str], device, max_length: int = 512) -> list[torch.Tensor]:
+def encode_flan_t5(prompts: list[str], device, max_length: int = 512, model_path: str = "google/flan-t5-xxl") -> list[torch.Tensor]:
     """-> list of [n_i, 4096] (padding removed), as FlanT5XXL.encode_texts_padded + TextCond(padding=False).  Each prompt
-    is encoded on its own, unpadded: the same states the padded, masked HF batch yields at the kept positions."""
-    tok, run = _load("google/flan-t5-xxl", str(device))
+    is encoded on its own, unpadded: the same states the padded, masked HF batch yields at the kept positions.
+    model_path: FlanT5XXL's `model_path` (text_encoder.py:137-146) -- the hub name, or a local directory."""
+    tok, run = _load(model_path, str(device))
     out = []
     for p in prompts:
         ids = tok(p, return_tensors="pt", truncation=True, max_length=max_length).input_ids[0]

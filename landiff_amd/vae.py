@@ -135,7 +135,9 @@ class VAEDecoder:
         else:
             self.cache = {}
             spans = [((0, 3) if i == 0 else (i * 2 + 1, i * 2 + 3)) for i in range((Tl - 1) // 2)]
-            n_frames = 4 * Tl - 3
+            # 9 frames from the first chunk, 8 from each later one; an even T leaves its last latent frame undecoded, as the
+            # reference's loop does (dif_infer.py:253-259: "Must be 13, 11 or 9" in infer_cfgs/2b.yaml)
+            n_frames = 1 + 8 * len(spans)
         P_total = n_frames * 8 * h * 8 * w
         frames = torch.empty(n_frames, 8 * h, 8 * w, 3, device=self.dev, dtype=torch.uint8)
         video = torch.empty(3, P_total, device=self.dev, dtype=torch.float32) if want_float else None

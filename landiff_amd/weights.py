@@ -140,7 +140,7 @@ def dit_spec(c: DiTConfig, control: bool) -> Spec:
     pd = c.patch * c.patch
     s = [("time_embed.0.weight", (te, d), "w"), ("time_embed.0.bias", (te,), "b"),
          ("time_embed.2.weight", (te, te), "w"), ("time_embed.2.bias", (te,), "b"),
-         ("mixins.pos_embed.pos_embedding", (1, c.seq_len, d), "pos"),
+         ("mixins.pos_embed.pos_embedding", (1, c.pos_rows, d), "pos"),
          ("mixins.patch_embed.proj.weight", (d, c.in_channels, c.patch, c.patch), "w"),
          ("mixins.patch_embed.proj.bias", (d,), "b"),
          ("mixins.patch_embed.text_proj.weight", (d, c.text_dim), "w"), ("mixins.patch_embed.text_proj.bias", (d,), "b")]
@@ -296,10 +296,7 @@ def resolve_ckpt_root(repo_root: str | None = None) -> str:
 def _sat_module(path_dir: str) -> dict:
     with open(os.path.join(path_dir, "latest")) as f:
         it = f.read().strip()
-    # a full pickle (argparse namespaces next to the tensors): torch >= 2.6 defaults to weights_only=True and would refuse it;
-    # the reference loads these trusted local files with the old default (dit_video_concat.py:1176, sat load_checkpoint)
-    sd = torch.load(os.path.join(path_dir, it, "mp_rank_00_model_states.pt"), map_location="cpu", weights_only=False)
-    return sd["module"]
+    return _load_pickle(os.path.join(path_dir, it, "mp_rank_00_model_states.pt"))["module"]
 
 
 def _sub(sd: dict, prefix: str) -> dict:
@@ -326,12 +323,41 @@ def load_tokenizer_encoder_state(path: str) -> dict:
     return out
 
 
-def load_diffusion_states(diffusion_dir: str, root: str) -> dict:
-    """Returns component state dicts from diffusion/<latest>/...pt plus the CogVideoX base DiT
-    (keys 'model.diffusion_model.*', prefix 'model.' stripped as dit_video_concat.py:1176-1189 does;
-    the control ckpt then overrides, load_checkpoint is non-strict) and the VAE."""
+def resolve_ckpt_path(path: str, root: str | None = None) -> str:
+    """A checkpoint path as the CLI / the YAML files give it: used as is when it exists (absolute, or relative to the working
+    directory -- the reference resolves "ckpts/LanDiff/..." against the cwd); otherwise its part below "ckpts/LanDiff/" is
+    looked up in the checkpoint root ($LANDIFF_HOME), so the shipped relative paths work from any directory."""
+    if os.path.exists(path):
+        return path
+    marker = "ckpts/LanDiff/"
+    norm = path.replace(os.sep, "/")
+    if marker in norm:
+        cand = os.path.join(root or resolve_ckpt_root(), norm.split(marker, 1)[1])
+        if os.path.exists(cand):
+            return cand
+    raise FileNotFoundError(f"checkpoint path {path!r} not found (cwd {os.getcwd()!r}; LANDIFF_HOME={os.environ.get('LANDIFF_HOME')!r})")
+
+
+def _load_pickle(path: str) -> dict:
+    # a full pickle (argparse namespaces next to the tensors): torch >= 2.6 defaults to weights_only=True and would refuse it;
+    # the reference loads these trusted local files with the old default (dit_video_concat.py:1176, sat load_checkpoint)
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_diffusion_states(diffusion_dir: str, root: str | None = None, *, base_dit_ckpt: str | None = None,
+                          vae_ckpt: str | None = None, tokenizer_ckpt: str | None = None) -> dict:
+    """Component state dicts of the diffusion stage, assembled in the reference's load order:
+      1. VideoVQWrap loads `tokenizer_ckpt` (tokenizer/model.safetensors, vq_warp.py:38-48), the first stage loads
+         `vae_ckpt`['state_dict'] (autoencoder.py:603-614), ControlDiffWarp loads `base_dit_ckpt`['module'] with the 'model.'
+         prefix stripped into BOTH the main and the control DiT (dit_video_concat.py:1176-1189);
+      2. sat load_checkpoint(diffusion_dir: `latest` -> <iter>/mp_rank_00_model_states.pt['module'], non-strict under
+         force_inference) then overrides whatever it carries (dif_infer.py:144).
+    base_dit_ckpt / vae_ckpt default to the layout of ckpts/README.md:27-45 under `root` (base: transformer/latest)."""
     mod = _sat_module(diffusion_dir)
-    base = _sat_module(os.path.join(root, "CogVideoX-2b-sat", "transformer"))
+    if base_dit_ckpt is not None:
+        base = _load_pickle(resolve_ckpt_path(base_dit_ckpt, root))["module"]
+    else:
+        base = _sat_module(os.path.join(root, "CogVideoX-2b-sat", "transformer"))
     base = _sub(base, "model.diffusion_model.")
     main = dict(base)
     main.update(_sub(mod, "model.main_model.diffusion_model."))
@@ -339,8 +365,55 @@ def load_diffusion_states(diffusion_dir: str, root: str) -> dict:
     ctrl = {k: v for k, v in base.items()}
     ctrl.update({k: v for k, v in ctrl_all.items() if not k.startswith("semantic_conditioner.")})
     sem = _sub(ctrl_all, "semantic_conditioner.")
-    tok = _sub(sem, "semantic_model.model.")
+    tok = {}
+    if tokenizer_ckpt:
+        from safetensors.torch import load_file
+        tok = {k: v for k, v in load_file(resolve_ckpt_path(tokenizer_ckpt, root)).items()
+               if k.startswith("decoder.") or k.startswith("quantizer.") or k in ("mean", "std")}
+    tok.update(_sub(sem, "semantic_model.model."))
     ups = {k: v for k, v in sem.items() if k.startswith("upsample_model.") or k.startswith("conv_out.")}
-    vae_sd = torch.load(os.path.join(root, CKPT_FILES["vae"]), map_location="cpu", weights_only=False)["state_dict"]   # lightning pickle
-    vae = {k: v for k, v in vae_sd.items() if k.startswith("decoder.")}
+    vae_path = resolve_ckpt_path(vae_ckpt, root) if vae_ckpt is not None else os.path.join(root, CKPT_FILES["vae"])
+    vae = {k: v for k, v in _load_pickle(vae_path)["state_dict"].items() if k.startswith("decoder.")}    # lightning pickle
+    vae.update({k: v for k, v in _sub(mod, "first_stage_model.").items() if k.startswith("decoder.")})
     return {"dit_main": main, "dit_control": ctrl, "tok": tok, "ups": ups, "vae": vae}
+
+
+def save_checkpoint_tree(root: str, states: dict, *, iteration: str = "1", base_iteration: str = "1000",
+                         split_base: bool = True) -> str:
+    """Writes component state dicts ({'llm','tok','ups','dit_main','dit_control','vae'}, e.g. init_pipeline_state) as a
+    checkpoint tree in the reference's layout (ckpts/README.md:27-45) -- the inverse of load_llm_state / load_diffusion_states:
+
+        <root>/llm/model.safetensors                                     Semantic1DLM state dict
+        <root>/tokenizer/model.safetensors                               VideoVQ state dict (decoder + quantizer halves given)
+        <root>/diffusion/{latest, <iteration>/mp_rank_00_model_states.pt}   ['module']: control DiT + semantic conditioner,
+                                                                         and the main DiT's own (non-base) keys
+        <root>/CogVideoX-2b-sat/transformer/{latest, <base_iteration>/mp_rank_00_model_states.pt}   ['module']: 'model.diffusion_model.*'
+        <root>/CogVideoX-2b-sat/vae/3d-vae.pt                            ['state_dict']: 'decoder.*'
+
+    split_base: the main DiT's weights go to the CogVideoX base checkpoint (as released: the main DiT is frozen and the control
+    checkpoint holds only what was trained); False writes them into the diffusion checkpoint as well (both orders must load
+    to the same result).  Synthetic-weight runs of the drop-in entry point (BASELINE configs[0]) and tests use this."""
+    import argparse
+    from safetensors.torch import save_file
+    c = lambda sd: {k: v.detach().cpu().contiguous() for k, v in sd.items()}
+    os.makedirs(os.path.join(root, "llm"), exist_ok=True)
+    os.makedirs(os.path.join(root, "tokenizer"), exist_ok=True)
+    if "llm" in states:
+        save_file(c(states["llm"]), os.path.join(root, CKPT_FILES["llm"]))
+    save_file(c(states["tok"]), os.path.join(root, CKPT_FILES["tokenizer"]))
+    ctl = "model.control_model.diffusion_model."
+    mod = {ctl + k: v for k, v in c(states["dit_control"]).items()}
+    mod.update({ctl + "semantic_conditioner.semantic_model.model." + k: v for k, v in c(states["tok"]).items()})
+    mod.update({ctl + "semantic_conditioner." + k: v for k, v in c(states["ups"]).items()})
+    base = {"model.diffusion_model." + k: v for k, v in c(states["dit_main"]).items()}
+    if not split_base:
+        mod.update({"model.main_model.diffusion_model." + k: v for k, v in c(states["dit_main"]).items()})
+    for d, it, sd in ((os.path.join(root, "diffusion"), iteration, mod),
+                      (os.path.join(root, "CogVideoX-2b-sat", "transformer"), base_iteration, base)):
+        os.makedirs(os.path.join(d, it), exist_ok=True)
+        with open(os.path.join(d, "latest"), "w") as f:
+            f.write(it)
+        torch.save({"module": sd, "args": argparse.Namespace(mode="inference")}, os.path.join(d, it, "mp_rank_00_model_states.pt"))
+    os.makedirs(os.path.join(root, "CogVideoX-2b-sat", "vae"), exist_ok=True)
+    torch.save({"state_dict": c(states["vae"])}, os.path.join(root, CKPT_FILES["vae"]))
+    return root

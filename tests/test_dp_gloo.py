@@ -72,3 +72,50 @@ def test_two_rank_gather():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res)
     assert sorted(sum((m for _, _, m in res), [])) == [0, 1, 2, 3]
+
+
+def _worker_eight(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from landiff_amd.pipeline import gather_prompt_frames, gather_rank_reports, rank_core_slice, shard_prompts
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for n_prompts in (5, 11, 8, 0):       # ranks 5..7 idle; uneven 2/1 split; one each; nothing at all
+        mine = shard_prompts(n_prompts, rank, world)
+        local = [torch.full((2, 4, 6, 3), 7 * p + 3, dtype=torch.uint8) for p in mine]
+        out = gather_prompt_frames(local, n_prompts, rank, world)
+        ok &= len(out) == n_prompts
+        ok &= all(tuple(out[p].shape) == (2, 4, 6, 3) and bool((out[p] == 7 * p + 3).all()) for p in range(n_prompts))
+    reports = gather_rank_reports({"rank": rank, "stage_seconds": {"dit": 10.0 + rank}, "frames_per_s": 3.0 - 0.01 * rank}, world)
+    ok &= [r["rank"] for r in reports] == list(range(world)) and reports[rank]["stage_seconds"]["dit"] == 10.0 + rank
+    cores = list(range(64))
+    slices = [rank_core_slice(r, world, cores) for r in range(world)]
+    ok &= sorted(sum(slices, [])) == cores and all(len(s) == 8 for s in slices) and slices[rank] == cores[8 * rank: 8 * rank + 8]
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok, None))
+
+
+def test_eight_rank_uneven_batches_and_rank_reports():
+    """BASELINE configs[3] geometry on CPU: 8 ranks (gloo), prompt batches that do not divide by 8 incl. ranks with no prompt and
+    an empty batch, the per-rank report gather of the N > 1 bench line, and the per-rank core slices."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker_eight, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert len(res) == 8 and all(ok for _, ok, _ in res)
+
+
+def test_rank_core_slices_are_disjoint_and_cover():
+    from landiff_amd.pipeline import rank_core_slice
+    cores = [0, 1, 2, 3, 8, 9, 10, 11, 16, 17]                         # a cpuset with holes, not a multiple of the world
+    s = [rank_core_slice(r, 4, cores) for r in range(4)]
+    assert s == [[0, 1], [2, 3], [8, 9], [10, 11]]
+    assert rank_core_slice(0, 1, cores) == cores and rank_core_slice(3, 16, cores) == cores    # fewer cores than ranks: no pinning

@@ -1,0 +1,275 @@
+"""The drop-in entry point (landiff.infer_video / llm_infer / dif_infer task API) run end to end on a synthetic
+checkpoint tree at BASELINE configs[0] sizes: tiny DiT, 8 latent frames, 64x64 latent, 2 DDIM steps.  CPU tests cover the
+config files, the checkpoint tree round trip and the teacher-forcing bookkeeping; the GPU test runs the CLI functions the way
+the reference's main() does and checks ids / latent / frames against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from facade_helpers import INFER_YAML, MODEL_YAML, ROOT, build_config0_workdir, config0_yaml
+
+
+def test_shipped_yaml_files_give_the_full_configuration():
+    from landiff_amd.config import PipelineConfig, load_diffusion_config
+    import dataclasses
+    c = load_diffusion_config(os.path.join(ROOT, MODEL_YAML), os.path.join(ROOT, INFER_YAML))
+    f = PipelineConfig.full()
+    assert dataclasses.replace(c.dit, pos_frames=0) == f.dit and c.dit.pos_frames == 13
+    assert (c.tok, c.ups, c.vae, c.sampler) == (f.tok, f.ups, f.vae, f.sampler)
+    assert c.image_size == (480, 720) and c.fps == 8 and c.bf16 and c.force_inference
+    assert c.t5_dir.endswith("CogVideoX-2b-sat/t5-v1_1-xxl") and c.vae_ckpt.endswith("vae/3d-vae.pt")
+    assert c.base_dit_ckpt.endswith("transformer/1000/mp_rank_00_model_states.pt") and c.tokenizer_ckpt.endswith("tokenizer/model.safetensors")
+    ref = "/root/reference/landiff/diffusion/configs/"
+    if os.path.isdir(ref):      # authoring container only: the reference's own files parse to the same configuration
+        r = load_diffusion_config(ref + "cogvideox_2b_control_theia_interpolate_video_vq.yaml", ref + "infer_cfgs/2b.yaml")
+        assert r == c
+
+
+def test_yaml_values_drive_the_shapes_and_bad_configs_are_refused(tmp_path):
+    import yaml
+    from landiff_amd.config import PipelineConfig, load_diffusion_config
+    want = config0_yaml(str(tmp_path))
+    got = load_diffusion_config(str(tmp_path / MODEL_YAML), str(tmp_path / INFER_YAML))
+    assert got.dit == want.dit.__class__(**{**want.dit.__dict__, "pos_frames": 8})
+    assert (got.tok, got.ups, got.vae, got.sampler) == (want.tok, want.ups, want.vae, want.sampler)
+    assert got.sampler.sampler == "ddim" and got.sampler.num_steps == 2 and got.image_size == (512, 512)
+    doc = yaml.safe_load(open(tmp_path / MODEL_YAML))
+    doc["model"]["sampler_config"]["target"] = "landiff.diffusion.sgm.modules.diffusionmodules.sampling.EulerEDMSampler"
+    yaml.safe_dump(doc, open(tmp_path / "bad.yaml", "w"))
+    with pytest.raises(AssertionError, match="EulerEDMSampler"):
+        load_diffusion_config(str(tmp_path / "bad.yaml"), str(tmp_path / INFER_YAML))
+    inf = yaml.safe_load(open(tmp_path / INFER_YAML))
+    inf["args"]["sampling_image_size"] = [480, 720]           # not 8x the DiT's latent grid
+    yaml.safe_dump(inf, open(tmp_path / "bad_infer.yaml", "w"))
+    with pytest.raises(AssertionError, match="sampling_image_size"):
+        load_diffusion_config(str(tmp_path / MODEL_YAML), str(tmp_path / "bad_infer.yaml"))
+
+
+def test_checkpoint_tree_round_trip_and_path_resolution(tmp_path, monkeypatch):
+    """save_checkpoint_tree writes the reference layout; the loaders read back exactly the component state dicts, whether the
+    main DiT lives in the CogVideoX base checkpoint (as released) or in the diffusion checkpoint as well."""
+    from landiff_amd.config import PipelineConfig, load_diffusion_config
+    from landiff_amd.weights import (init_pipeline_state, load_diffusion_states, load_llm_state, resolve_ckpt_path,
+                                     save_checkpoint_tree)
+    cfg = PipelineConfig.tiny()
+    st = init_pipeline_state(cfg, seed=3)
+    for split in (True, False):
+        root = str(tmp_path / f"w{int(split)}" / "ckpts" / "LanDiff")
+        save_checkpoint_tree(root, st, split_base=split)
+        for rel in ("llm/model.safetensors", "tokenizer/model.safetensors", "diffusion/latest", "diffusion/1/mp_rank_00_model_states.pt",
+                    "CogVideoX-2b-sat/transformer/latest", "CogVideoX-2b-sat/transformer/1000/mp_rank_00_model_states.pt",
+                    "CogVideoX-2b-sat/vae/3d-vae.pt"):
+            assert os.path.exists(os.path.join(root, rel)), rel
+        assert open(os.path.join(root, "diffusion/latest")).read() == "1"            # md5("1") in ckpts/CHECKSUM.md5:13
+        out = load_diffusion_states(os.path.join(root, "diffusion"), root,
+                                    base_dit_ckpt="ckpts/LanDiff/CogVideoX-2b-sat/transformer/1000/mp_rank_00_model_states.pt",
+                                    vae_ckpt="ckpts/LanDiff/CogVideoX-2b-sat/vae/3d-vae.pt",
+                                    tokenizer_ckpt="ckpts/LanDiff/tokenizer/model.safetensors")
+        for part in ("dit_main", "tok", "ups", "vae"):
+            assert set(out[part]) == set(st[part]), part
+            assert all(torch.equal(out[part][k], st[part][k]) for k in st[part]), part
+        assert all(torch.equal(out["dit_control"][k], st["dit_control"][k]) for k in st["dit_control"])
+        llm = load_llm_state(os.path.join(root, "llm/model.safetensors"))
+        assert all(torch.equal(llm[k], st["llm"][k]) for k in st["llm"])
+    # relative "ckpts/LanDiff/..." paths: the cwd first (as the reference), then $LANDIFF_HOME
+    work = tmp_path / "w1"
+    monkeypatch.chdir(work)
+    assert resolve_ckpt_path("ckpts/LanDiff/llm/model.safetensors") == "ckpts/LanDiff/llm/model.safetensors"
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("LANDIFF_HOME", str(work / "ckpts" / "LanDiff"))
+    assert resolve_ckpt_path("ckpts/LanDiff/llm/model.safetensors") == str(work / "ckpts" / "LanDiff" / "llm/model.safetensors")
+    with pytest.raises(FileNotFoundError):
+        resolve_ckpt_path("ckpts/LanDiff/llm/other.safetensors")
+
+
+def test_teacher_sequence_matches_the_oracle_token_layout():
+    """teacher_forcing feeds `token[i]` of the reference's full sequence (lm_model.py:506-507): special ids at the forced slots,
+    ground-truth visual ids elsewhere."""
+    from landiff.llm.llm_infer import ARSampleCfg, CodeTask, teacher_sequence
+    from landiff_amd.config import LLMConfig
+    from landiff_amd.llm import forced_token_schedule
+    c = LLMConfig.tiny()
+    S = 9
+    full_len, forced, _, n_vis = forced_token_schedule(c, S, c.segment_length)
+    gt = torch.arange(n_vis) % c.visual_vocab
+    seq = teacher_sequence(c, S, c.segment_length, gt)
+    assert seq.shape == (full_len - S - 1,)
+    assert seq[0] == gt[0] and seq[c.iframe_len] == c.END_I and seq[c.iframe_len + 1] == c.START_P and seq[-1] == c.EOS
+    assert torch.equal(seq[seq < c.visual_vocab], gt)
+    skipped = teacher_sequence(c, S, c.segment_length, gt, skip=c.iframe_len + 2)
+    assert torch.equal(skipped, seq[c.iframe_len + 2:])
+    with pytest.raises(AssertionError):
+        teacher_sequence(c, S, c.segment_length, gt[:-1])
+    assert str(ARSampleCfg()) == "default" and ARSampleCfg(cfg=7.5, top_k=3).to_dict() == {"top_k": 3, "cfg": 7.5}
+    assert CodeTask("x.npy", "p", 1).sample_cfg == ARSampleCfg()
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    work = str(tmp_path_factory.mktemp("config0"))
+    cfg, states = build_config0_workdir(work)
+    return work, cfg, states
+
+
+@pytest.mark.gpu
+def test_infer_video_entry_point_config0(cuda, workdir, monkeypatch):
+    """BASELINE configs[0] through the reference's CLI functions (landiff/infer_video.py:61-114): llm_infer(args) writes the
+    token .npy, infer_diffusion(args, tokens) writes the video; both wrappers read the checkpoint tree, the YAML files and the T5
+    directories from the working directory like the reference.  Checked against the oracle: token ids exact (confident head),
+    latent within 2x the bf16 oracle's own distance from fp32, frames within a few grey levels."""
+    import landiff.infer_video as iv
+    from landiff.utils import set_seed_for_single_process
+    from landiff_amd.llm import forced_token_schedule
+    from landiff_amd.text import encode_flan_t5, encode_t5_v11
+    from oracle.llm import LLMOracle
+    from oracle.pipeline import PipelineOracle
+    work, cfg, states = workdir
+    monkeypatch.chdir(work)
+    monkeypatch.delenv("LANDIFF_HOME", raising=False)
+    monkeypatch.setattr(iv, "build_llm", lambda: cfg.llm)
+    prompt, seed = "a red bird flying over the river", 7
+    args = iv.parse_args(["--prompt", prompt, "--save_file_name", "results/video", "--seed", str(seed), "--cfg", "7.5", "--motion_score", "0.1"])
+    assert args.llm_ckpt == "ckpts/LanDiff/llm/model.safetensors" and args.diffusion_ckpt == "ckpts/LanDiff/diffusion"
+    tokens = iv.llm_infer(args)
+    assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.shape == (cfg.tok.num_latent_tokens,)
+    assert np.array_equal(np.load("results/video.npy"), tokens.cpu().numpy())
+    captured = {}
+    real_save = iv.save_video_tensor
+    monkeypatch.setattr(iv, "save_video_tensor", lambda v, p, fps=8: (captured.update(video=v, fps=fps), real_save(v, p, fps=fps))[1])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        iv.infer_diffusion(args, tokens)
+    video = captured["video"]
+    d = cfg.dit
+    n_frames = 1 + 8 * ((d.latent_frames - 1) // 2)
+    assert video.shape == (3, n_frames, 8 * d.latent_h, 8 * d.latent_w) and video.device.type == "cpu" and captured["fps"] == 8
+    assert float(video.min()) >= 0.0 and float(video.max()) <= 1.0
+    assert os.path.exists("results/video.mp4") or (os.path.exists("results/video.avi") and os.path.exists("results/video.frames.npy"))
+
+    # ---- token ids vs the oracle: teacher-forced on the device's history, its multinomial on the same device RNG stream ----
+    text = encode_flan_t5([prompt], cuda, max_length=cfg.llm.max_cond_tokens, model_path=cfg.llm.text_encoder_path)[0]
+    S = text.shape[0] + 3
+    full_len, forced, _, n_vis = forced_token_schedule(cfg.llm, S, cfg.llm.segment_length)
+    raw = iter(tokens.cpu().tolist())
+    fed = [forced[i] if i in forced else next(raw) for i in range(S + 1, full_len)]
+    gen = torch.Generator(device=cuda); gen.manual_seed(seed)
+    ref_ids = LLMOracle(states["llm"], cfg.llm, torch.bfloat16).sample(
+        text.float().cpu(), num_frames=cfg.llm.segment_length, guidance_scale=7.5, motion_score=0.1, teacher_tokens=torch.tensor(fed),
+        multinomial_fn=lambda p: torch.multinomial(p.to(cuda), 1, generator=gen).cpu())
+    assert torch.equal(ref_ids.reshape(-1), tokens.cpu()), int((ref_ids.reshape(-1) != tokens.cpu()).sum())
+
+    # ---- latent + frames vs the oracle on the same tokens, T5 states and initial noise ----
+    ctx = encode_t5_v11([prompt], os.path.join(work, "ckpts/LanDiff/CogVideoX-2b-sat/t5-v1_1-xxl"), d.text_len, cuda)
+    set_seed_for_single_process(seed)
+    noise = torch.randn(1, d.latent_frames, d.in_channels, d.latent_h, d.latent_w, device=cuda, dtype=torch.float32).cpu()
+    # the wrapper's own latent, through the CogWrapper level of the API
+    from landiff.diffusion.dif_infer import CogModelInferWrapper
+    wrap = CogModelInferWrapper(ckpt_path=args.diffusion_ckpt)
+    out = wrap.init_infer_model.forward(dict(caption=prompt, video=None), seed=seed, semantic_token=tokens)
+    assert out.latent.shape == (1, d.latent_frames, d.in_channels, d.latent_h, d.latent_w) and out.latent.dtype == torch.bfloat16
+    assert torch.equal(out.video.cpu()[0], video), "CogWrapper.forward and CogModelInferWrapper.forward disagree"
+    orc16, orc32 = PipelineOracle(cfg, states, torch.bfloat16), PipelineOracle(cfg, states, torch.float32)
+    z16 = orc16.latent(tokens.cpu(), ctx.float().cpu(), noise=noise)
+    z32 = orc32.latent(tokens.cpu(), ctx.float().cpu(), noise=noise)
+    rel = lambda a, b: ((a.float().cpu() - b.float()).abs().max() / b.float().abs().max()).item()
+    floor, err = rel(z16, z32), rel(out.latent, z32)
+    assert err < max(2 * floor, 2e-2), (err, floor)
+    video32, frames32 = orc32.frames(z32)
+    assert video32.shape == video.shape
+    assert (video - video32).abs().mean().item() < 2e-2
+    frames = np.load("results/video.frames.npy") if os.path.exists("results/video.frames.npy") else None
+    if frames is not None:
+        assert frames.shape == tuple(frames32.shape) and np.abs(frames.astype(int) - frames32.numpy().astype(int)).mean() < 6.0
+        assert np.array_equal(frames, (video.permute(1, 2, 3, 0) * 255).clip(0, 255).numpy().astype(np.uint8))     # uint8 truncation
+
+
+@pytest.mark.gpu
+def test_wrapper_teacher_forcing_first_frame_and_precomputed_text(cuda, workdir, monkeypatch):
+    """ARSampleCfg.teacher_forcing / use_gt_first_frame through ArModelInferWrapper, with pre-computed text states: teacher-forced
+    logits do not depend on the sampled ids, so two seeds see the same fed-back history; the first-frame ids lead the result."""
+    from landiff.llm.llm_infer import ARSampleCfg, ArModelInferWrapper, CodeTask
+    work, cfg, states = workdir
+    monkeypatch.chdir(work)
+    c = cfg.llm
+    g = torch.Generator().manual_seed(1)
+    states_txt = torch.randn(5, c.text_dim, generator=g)
+    llm = ArModelInferWrapper("ckpts/LanDiff/llm/model.safetensors", c, text_encoder=lambda prompts: [states_txt.to(cuda)])
+    n_vis = cfg.tok.num_latent_tokens
+    gt = torch.randint(0, c.visual_vocab, (n_vis,), generator=g)
+    mk = lambda seed, **kw: CodeTask("x.npy", "ignored", seed, gt_tokens=gt, sample_cfg=ARSampleCfg(cfg=7.5, motion_score=0.1, num_frames=c.segment_length, **kw))
+    a = llm(mk(3, teacher_forcing=True)).result
+    b = llm(mk(3, teacher_forcing=True)).result
+    assert a.shape == (n_vis,) and torch.equal(a, b)                                   # deterministic
+    free = llm(mk(3)).result
+    assert not torch.equal(a, free)                                                    # the fed-back history matters
+    # teacher forcing: every step's distribution is conditioned on gt, so resampling one seed changes ids but a greedy-like
+    # confident head still tracks gt-conditioned argmaxes -- both seeds agree wherever the head is confident
+    a2 = llm(mk(4, teacher_forcing=True)).result
+    assert (a == a2).float().mean().item() > 0.5
+    ff = llm(mk(3, use_gt_first_frame=True)).result
+    assert ff.shape == (n_vis,) and torch.equal(ff[: c.iframe_len], gt[: c.iframe_len])
+    both = llm(mk(3, use_gt_first_frame=True, teacher_forcing=True)).result
+    assert torch.equal(both[: c.iframe_len], gt[: c.iframe_len]) and both.shape == (n_vis,)
+    with pytest.raises(ValueError, match="gt_tokens"):
+        llm(CodeTask("x.npy", "p", 1, sample_cfg=ARSampleCfg(cfg=7.5, motion_score=0.1, num_frames=c.segment_length, teacher_forcing=True)))
+    with pytest.raises(ValueError, match="motion_score"):
+        llm(CodeTask("x.npy", "p", 1, sample_cfg=ARSampleCfg(cfg=7.5, num_frames=c.segment_length)))
+    with pytest.raises(AssertionError, match="shape mismatch"):
+        from landiff_amd.config import LLMConfig
+        ArModelInferWrapper("ckpts/LanDiff/llm/model.safetensors", LLMConfig.tiny())
+
+
+@pytest.mark.gpu
+def test_cogwrapper_feature_and_video_conditioning(cuda, workdir, monkeypatch):
+    """CogWrapper.forward's other conditioning inputs (dif_infer.py:152-170, dit_video_concat.py:939-975):
+    semantic_feature_before_upsample = the detokenizer features of the tokens gives the token path's video bit for bit; a
+    conditioning video goes through feature extractor -> tokenizer encoder -> nearest code -> decoder; without an extractor the
+    mp4 path says what is missing."""
+    from landiff.diffusion.dif_infer import CogModelInferWrapper, VideoTask
+    from landiff_amd.tokenizer_encoder import TokenizerEncoder
+    from landiff_amd.weights import init_state, tokenizer_encoder_spec
+    from safetensors.torch import load_file, save_file
+    work, cfg, states = workdir
+    monkeypatch.chdir(work)
+    tc, d = cfg.tok, cfg.dit
+    # the released tokenizer file holds encoder + decoder + quantizer: add a synthetic encoder half to the tree
+    tok_file = "ckpts/LanDiff/tokenizer/model.safetensors"
+    sd = load_file(tok_file)
+    enc = init_state(tokenizer_encoder_spec(tc), 77)
+    enc["quantizer._codebook.embed"] = sd["quantizer._codebook.embed"]
+    save_file({**{k: v.contiguous() for k, v in enc.items()}, **sd}, tok_file)
+    g = torch.Generator().manual_seed(2)
+    ctx_states = torch.randn(1, d.text_len, d.text_dim, generator=g)
+    feats = torch.randn(tc.temporal, tc.out_channels, tc.grid_h, tc.grid_w, generator=g)
+    seen = {}
+    def extractor(images):
+        seen["shape"], seen["dtype"] = tuple(images.shape), images.dtype
+        seen["pad"] = int(images[0, 0, -1, -1])
+        return feats.to(cuda)
+    wrap = CogModelInferWrapper("ckpts/LanDiff/diffusion", text_encoder=lambda p: ctx_states.to(cuda), feature_extractor=extractor)
+    cw = wrap.init_infer_model
+    tokens = torch.randint(0, tc.codebook_size, (tc.num_latent_tokens,), generator=g).to(cuda)
+    base = cw.forward(dict(caption="p", video=None), seed=5, semantic_token=tokens)
+    f = cw.detok.index_to_feature(tokens).permute(0, 3, 1, 2)[None]                      # [1, T, C, h, w]
+    same = cw.forward(dict(caption="p", video=None), seed=5, semantic_feature_before_upsample=f)
+    assert torch.equal(base.video, same.video) and torch.equal(base.latent, same.latent)
+    # seed None: hashed from the prompt (stable across processes), different prompts -> different noise
+    h1 = cw.forward(dict(caption="p", video=None), semantic_token=tokens)
+    h2 = cw.forward(dict(caption="p", video=None), semantic_token=tokens)
+    h3 = cw.forward(dict(caption="q", video=None), semantic_token=tokens)
+    assert torch.equal(h1.latent, h2.latent) and not torch.equal(h1.latent, h3.latent)
+    # video conditioning: 20 input frames at 96x128 -> 8 sampled frames, padded to 128x128 with grey 127
+    mp4 = torch.rand(1, 3, 20, 96, 128, generator=g)
+    task = wrap(VideoTask("v.mp4", "p", 5, mp4=mp4))
+    assert seen == {"shape": (d.latent_frames, 3, 128, 128), "dtype": torch.uint8, "pad": 127}
+    want_tokens = TokenizerEncoder({**enc}, tc, cuda).encode_to_index(feats.to(cuda))
+    want = cw.forward(dict(caption="p", video=None), seed=5, semantic_token=want_tokens)
+    assert torch.equal(task.result, want.video.cpu()[0])
+    bare = CogModelInferWrapper("ckpts/LanDiff/diffusion", text_encoder=lambda p: ctx_states.to(cuda))
+    with pytest.raises(NotImplementedError, match="Theia"):
+        bare(VideoTask("v.mp4", "p", 5, mp4=mp4))
+    with pytest.raises(KeyError):
+        bare(VideoTask("v.mp4", "p", 5))

@@ -180,3 +180,125 @@ def test_tokenizer_encoder_full_size_causality(cuda):
         assert torch.equal(out[:keep], base[:keep]), f
         assert not torch.equal(out[keep:keep + nP], base[keep:keep + nP]), f
     assert torch.isfinite(base.float()).all()
+
+
+def _rel(a, b):
+    return ((a.float().cpu() - b.float()).abs().max() / b.float().abs().max()).item()
+
+
+def test_llm_full_size_prefill_and_decode_vs_oracle(cuda):
+    """The AR decoder at its real size (24 blocks x 2048, MLP 11008, vocabulary 2055, CFG pair): prefill of 64 text tokens + the
+    conditioning prefix, then 3 teacher-forced decode steps -- CFG logits of the HIP path (bf16 GEMM prefill, fused GEMV decode
+    steps, split-K KV attention with in-kernel RoPE + append) against the fp32 oracle on the host cores, within 2x the bf16
+    oracle's own distance from it."""
+    from landiff_amd.config import LLMConfig
+    from landiff_amd.llm import LLMRunner
+    from landiff_amd.weights import init_state, llm_spec
+    from oracle.llm import LLMOracle, rope_table
+    cfg = LLMConfig()
+    sd_dev = init_state(llm_spec(cfg), 3, dtype=torch.bfloat16, device=cuda)
+    sd = {k: v.cpu() for k, v in sd_dev.items()}                      # the same bf16 weights for the oracle (4 GB)
+    run = LLMRunner(sd_dev, cfg, cuda)
+    del sd_dev
+    g = torch.Generator().manual_seed(4)
+    text = torch.randn(64, cfg.text_dim, generator=g).to(torch.bfloat16)
+    n_steps = 3
+    fed = torch.randint(0, cfg.visual_vocab, (2000,), generator=g)   # teacher-fed ids (only the first n_steps matter below)
+    log = []
+    run.sample(text.to(cuda), guidance_scale=7.5, motion_score=0.1, seed=42, logits_log=log, teacher_fed=fed.to(cuda))
+    dev = torch.cat(log[: n_steps + 1], 0).cpu()                       # CFG logits of the prefill + 3 decode steps
+    torch.set_num_threads(min(64, max(torch.get_num_threads(), (torch.get_num_threads() * 8))))
+
+    def oracle_logits(dtype):
+        orc = LLMOracle(sd, cfg, dtype)
+        with torch.no_grad():
+            feats = orc.prefix_features(text.float(), 13.0, 0.1, True)
+            S = feats.shape[1] - 1
+            cos, sin = rope_table(cfg.head_dim, S + 2 + n_steps, cfg.rope_theta)
+            cache = [None] * cfg.num_layers
+            emb = sd["visual_embedding_model.tok_emb_code.weight"]
+            out = []
+            lg = orc.gpt_step(feats, cache, cos[None, : S + 1], sin[None, : S + 1]).float()
+            out.append(lg[1:] + 7.5 * (lg[:1] - lg[1:]))
+            for it in range(n_steps):
+                f = emb[fed[it]].float().reshape(1, 1, -1)
+                pos = S + 1 + it
+                lg = orc.gpt_step(torch.cat([f, f], 0), cache, cos[None, pos:pos + 1], sin[None, pos:pos + 1]).float()
+                out.append(lg[1:] + 7.5 * (lg[:1] - lg[1:]))
+        return torch.cat(out, 0)
+
+    ref32 = oracle_logits(torch.float32)
+    ref16 = oracle_logits(torch.bfloat16)
+    assert dev.shape == ref32.shape == (n_steps + 1, cfg.vocab)
+    floor, err = _rel(ref16, ref32), _rel(dev, ref32)
+    print(f"full-size LLM CFG logits: err {err:.4f}, bf16-oracle floor {floor:.4f}, |logit|max {ref32.abs().max():.2f}")
+    assert err < max(2 * floor, 2e-2), (err, floor)
+    for i in range(n_steps + 1):                                       # every step on its own, prefill and decode alike
+        assert _rel(dev[i], ref32[i]) < max(2 * _rel(ref16[i], ref32[i]), 3e-2), i
+
+
+def test_titok_decoder_layer_full_size_vs_oracle(cuda):
+    """One full-size TiTok decoder layer in context (18 768 tokens = 13 x 30 x 45 mask tokens + 1218 latent tokens, width 768,
+    12 heads, 3D RoPE, frame-block mask with tile skipping): VQ lookup -> decoder_embed -> ln_pre -> block -> ln_post -> tanh
+    FFN head, HIP path vs the fp32 oracle, within 2x the bf16 oracle's own distance."""
+    import dataclasses
+    from landiff_amd.config import TokenizerConfig, UpsamplerConfig
+    from landiff_amd.detokenizer import Detokenizer
+    from landiff_amd.weights import init_state, tokenizer_spec, upsampler_spec
+    from oracle.tokenizer import DetokenizerOracle
+    tc = dataclasses.replace(TokenizerConfig(), layers=1)
+    uc = UpsamplerConfig.tiny()                                        # (not exercised: index_to_feature stops before the upsampler)
+    tok_sd = init_state(tokenizer_spec(tc), 21)
+    ups_sd = init_state(upsampler_spec(uc), 22)
+    tokens = torch.randint(0, tc.codebook_size, (tc.num_latent_tokens,), generator=torch.Generator().manual_seed(6))
+    det = Detokenizer(tok_sd, ups_sd, tc, uc, cuda)
+    got = det.index_to_feature(tokens.to(cuda)).float().cpu()         # [T, h, w, C]
+    torch.set_num_threads(min(64, max(torch.get_num_threads(), torch.get_num_threads() * 8)))
+    with torch.no_grad():
+        ref32 = DetokenizerOracle(tok_sd, ups_sd, tc, uc, torch.float32).index_to_feature(tokens.reshape(1, 1, -1))[0]
+        ref16 = DetokenizerOracle(tok_sd, ups_sd, tc, uc, torch.bfloat16).index_to_feature(tokens.reshape(1, 1, -1))[0]
+    ref32, ref16 = ref32.permute(0, 2, 3, 1).float(), ref16.permute(0, 2, 3, 1).float()   # [T, C, h, w] -> [T, h, w, C]
+    assert got.shape == ref32.shape == (tc.temporal, tc.grid_h, tc.grid_w, tc.out_channels)
+    floor, err = _rel(ref16, ref32), _rel(got, ref32)
+    print(f"full-size TiTok layer: err {err:.4f}, bf16-oracle floor {floor:.4f}")
+    assert err < max(2 * floor, 1e-2), (err, floor)
+    # frame causality survives at full size: frame 0's features do not depend on the P tokens (masked keys contribute exactly 0)
+    t2 = tokens.clone()
+    t2[tc.iframe_tokens:] = (t2[tc.iframe_tokens:] + 1) % tc.codebook_size
+    got2 = det.index_to_feature(t2.to(cuda)).float().cpu()
+    assert torch.equal(got2[0], got[0]) and not torch.equal(got2[1], got[1])
+
+
+def test_vae_level0_resblock_full_resolution_vs_oracle(cuda):
+    """One level-0 resblock of the 3D-VAE decoder at 480 x 720 (128 channels, 4 frames = half a chunk): SpatialNorm3D with the
+    latent-resolution conv_y / conv_b gather + swish, causal 3x3x3 conv with the replicated-first-frame halo, twice, + residual
+    -- HIP path vs the fp32 oracle (the unit BASELINE.md section 3 names for the CPU baseline), 2x-floor rule."""
+    from landiff_amd.config import VAEConfig
+    from landiff_amd.vae import VAEDecoder, ZQ_PAD
+    from landiff_amd.weights import _res3d, init_state
+    from oracle.vae import VAEDecoderOracle
+    cfg = VAEConfig()
+    C, T, H, W = 128, 4, 480, 720
+    Tz, hz, wz = 1, 60, 90
+    p = "decoder.up.0.block.1."
+    sd = init_state(_res3d(p, C, C, cfg.z_channels), 31)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, C, T, H, W, generator=g).to(torch.bfloat16)
+    zq = torch.randn(1, cfg.z_channels, Tz, hz, wz, generator=g).to(torch.bfloat16)
+    dec = VAEDecoder(sd, cfg, cuda)
+    x_cl = x[0].permute(1, 2, 3, 0).reshape(T * H * W, C).contiguous().to(cuda)
+    z_cl = torch.zeros(Tz * hz * wz, ZQ_PAD, device=cuda, dtype=torch.bfloat16)
+    z_cl[:, : cfg.z_channels] = zq[0].permute(1, 2, 3, 0).reshape(-1, cfg.z_channels).to(cuda)
+    out = dec._resblock(x_cl, p, C, C, T, H, W, z_cl, (Tz, hz, wz), True)
+    got = out.view(T, H, W, C).permute(3, 0, 1, 2).float().cpu()
+    del dec, out, x_cl
+    torch.set_num_threads(min(64, max(torch.get_num_threads(), torch.get_num_threads() * 8)))
+    with torch.no_grad():
+        ref32 = VAEDecoderOracle(sd, cfg, torch.float32).resblock(x.float(), zq.float(), p, C, C, True)[0]
+        ref16 = VAEDecoderOracle(sd, cfg, torch.bfloat16).resblock(x, zq, p, C, C, True)[0].float()
+    assert got.shape == ref32.shape == (C, T, H, W)
+    floor, err = _rel(ref16, ref32), _rel(got, ref32)
+    mean_err = (got - ref32).abs().mean().item() / ref32.abs().mean().item()
+    print(f"level-0 VAE resblock 480x720: err {err:.4f} (mean {mean_err:.5f}), bf16-oracle floor {floor:.4f}")
+    assert err < max(2 * floor, 2e-2), (err, floor)
+    assert mean_err < 5e-3, mean_err
