@@ -25,9 +25,13 @@ def parse_args(argv=None):
 
 
 def llm_infer(args):
-    llm = ArModelInferWrapper(args.llm_ckpt, build_llm())
+    llm_model_cfg = build_llm()
+    llm = ArModelInferWrapper(args.llm_ckpt, llm_model_cfg)
+    # one segment of semantic frames = one 49-frame clip: 13 for the shipped configuration (ARSampleCfg's default, which the
+    # reference's llm_infer relies on); a configuration with another segment length (BASELINE configs[0]: 8) decodes its own
     task = CodeTask(save_file_name=f"{args.save_file_name}.npy", prompt=args.prompt, seed=args.seed,
-                    sample_cfg=ARSampleCfg(temperature=1.0, cfg=args.cfg, motion_score=args.motion_score))
+                    sample_cfg=ARSampleCfg(temperature=1.0, cfg=args.cfg, motion_score=args.motion_score,
+                                           num_frames=llm_model_cfg.segment_length))
     task = llm(task)
     tokens = task.result.reshape(-1)
     path = Path(task.save_file_name)

