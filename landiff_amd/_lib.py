@@ -6,7 +6,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void_p, c_float, c_double
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblandiff_hip.so")
+# LANDIFF_HIP_LIB: another build of the same library (tools/: A/B of compile-time variants); the product never sets it
+LIB_PATH = os.environ.get("LANDIFF_HIP_LIB") or os.path.join(_HERE, "liblandiff_hip.so")
 
 
 class LandiffHipError(RuntimeError):

@@ -52,6 +52,7 @@ struct GemmParams {
   int H, W_, Hp, Wp, Cin, kH, kW;   // output H,W; padded input Hp,Wp
   int group_m;                      // tile-raster group height (L2 locality)
   int m_begin;                      // first output row of this launch (rows stay absolute: M is the end row)
+  int abl;                          // LD_GEMM_ABL (timing experiments on the 8-phase loop only; results are wrong when set): 1 no staging, 2 no fragment reads, 4 no barriers, 8 no MFMAs
   // fp8 (e4m3) operands: A and W are byte matrices (lda in bytes), dequantised by per-row / per-output-channel scales
   const float* scale_a;             // [M]
   const float* scale_w;             // [N]
@@ -707,6 +708,324 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   else gemm_epilogue<MI, NI, EPI>(p, acc, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
 }
 
+// Two 1 KB LDS-DMA pieces of a half-tile through a raw buffer descriptor (rebuilt from its scalars at every use: loop-invariant
+// SGPR values for the compiler): per-lane byte offsets o0 / o1, wave-uniform K offset `ko` in an SGPR -- no vector ALU per piece.
+template <int OFF>
+__device__ __forceinline__ void stage_pieces(const bf16_t* base, int bytes, char* lds, uint32_t o0, uint32_t o1, int ko) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + OFF), 16, o0, ko, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + OFF + 1024), 16, o1, ko, 0, 0);
+}
+
+// Register-direct epilogue of the 8-phase kernel (EPI_BIAS / EPI_GELU / EPI_GATE): no LDS round trip.  The kernel runs its MFMAs
+// with the operands SWAPPED (W fragment first), so an accumulator block is C^T: a lane holds four consecutive COLUMNS of one
+// row, and stages its W rows permuted (see ld_gemm8p_kernel) so that the two blocks of a column pair are adjacent:
+//   acc[i][j][r] = C[row0 + 16 i + (lane & 15)][col0w + 32 (j >> 1) + 8 (lane >> 4) + 4 (j & 1) + r]
+// i.e. per (i, column pair) a lane owns 8 consecutive columns = one 16-byte bf16 store, and its epilogue operands (bias, gate,
+// residual, control add) are 16-byte loads at the same place.  Per element the operations and their order are those of
+// gemm_epilogue_core's specialised path: results are bit-identical to the LDS-staged epilogue.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4_t (&acc)[8][4], int lane, int row0, int col0w) {
+  const int r16 = lane & 15, g4 = lane >> 4;
+  int bnd = 0, b0 = 0;
+  if constexpr (EPI == EPI_GATE) {
+    b0 = row0 / p.rows_per_batch;
+    bnd = (b0 + 1) * p.rows_per_batch;
+  }
+  float bias[2][8];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int gn0 = col0w + 32 * pp + 8 * g4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[pp][e] = 0.f;
+    if (p.bias && gn0 < p.N) {
+      const u32x4_t bw = *(const u32x4_t*)(p.bias + gn0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias[pp][2 * e] = bf_lo(bw[e]); bias[pp][2 * e + 1] = bf_hi(bw[e]); }
+    }
+  }
+  // two row blocks x both column pairs per group: the two 64-byte halves of a row's 128-byte line leave back to back
+  auto group = [&](auto i0c) {
+    constexpr int i0 = decltype(i0c)::value;
+    u32x4_t g[2][2], rs[2][2], ad[2][2];
+    if constexpr (EPI == EPI_GATE) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const int gm = row0 + (i0 + ii) * 16 + r16, gn0 = col0w + 32 * pp + 8 * g4;
+          g[ii][pp] = rs[ii][pp] = ad[ii][pp] = (u32x4_t){0u, 0u, 0u, 0u};
+          if (gm < p.M && gn0 < p.N) {
+            const int b = gm >= bnd ? b0 + 1 : b0;
+            const int rin = gm - b * p.rows_per_batch;
+            g[ii][pp] = *(const u32x4_t*)(p.gate + b * p.gate_bstride + (rin < p.text_len ? p.gate_off_txt : p.gate_off_img) + gn0);
+            rs[ii][pp] = *(const u32x4_t*)((const bf16_t*)p.resid + (long)gm * p.ldr + gn0);
+            if (p.add2) ad[ii][pp] = *(const u32x4_t*)(p.add2 + (long)gm * p.ldadd + gn0);
+          }
+        }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        const int gm = row0 + (i0 + ii) * 16 + r16, gn0 = col0w + 32 * pp + 8 * g4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[i0 + ii][2 * pp][e]; v[4 + e] = acc[i0 + ii][2 * pp + 1][e]; }
+        u32x4_t ow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ld_f32x2_t x = rbf2((ld_f32x2_t){v[2 * e], v[2 * e + 1]} + (ld_f32x2_t){bias[pp][2 * e], bias[pp][2 * e + 1]});      // bf16 Linear output
+          if constexpr (EPI == EPI_GELU) x = act_gelu_tanh2(x);
+          if constexpr (EPI == EPI_GATE) {
+            x = rbf2(x * unpack_bf16x2(g[ii][pp][e]));
+            x = unpack_bf16x2(rs[ii][pp][e]) + x;
+            if (p.add2) x = rbf2(x) + unpack_bf16x2(ad[ii][pp][e]);
+          }
+          ow[e] = pack_bf16x2(x[0], x[1]);
+        }
+        if (gm < p.M && gn0 < p.N) {
+          if (p.abl & 16) *(u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0) = ow;
+          else __builtin_nontemporal_store(ow, (u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0));
+        }
+      }
+  };
+  group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 2>{});
+  group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 6>{});
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8-phase main loop (round 3; LD_GEMM_TILE=8): the 256x256x64 tile / 8 waves (2 x 4, 128 x 64 per wave) / 16x16x32 MFMAs of
+// ld_gemm_kernel<256,256,2,4,...,M16> with the staging PIPELINED through the K loop instead of issued tile by tile:
+//   * LDS = 2 K-tile buffers x 4 half-tile slots of 16 KB: A_h (h = 0, 1) holds, for BOTH wave rows wr, the 64 tile rows
+//     wr * 128 + h * 64 .. + 64 (local row wr * 64 + r); B_g (g = 0, 1) holds, for ALL FOUR wave columns wc, the 32 tile
+//     columns wc * 64 + g * 32 .. + 32 (local row wc * 32 + r).  Which tile row lands in which slot is free -- the LDS-DMA
+//     source address is per lane -- and this choice makes every one of a K-tile's four phases read ONE half-tile of A and ONE
+//     of W for the whole workgroup, so a slot is dead long before its K-tile is finished and can be re-staged early, while
+//     a wave's output stays 128 contiguous rows x 64 contiguous columns (the epilogues, incl. the fused qkv head split, are
+//     those of ld_gemm_kernel).
+//   * a K-tile = 4 phases of 16 MFMAs (one 64 x 32 quadrant of the wave tile x K = 64):
+//       ph0: read B_g0 (4 ds_read_b128) + A_h0 (8)   stage B_1(t+1)   MFMA (h0, g0)
+//       ph1: read B_g1 (4)                           stage A_1(t+1)   MFMA (h0, g1)
+//       ph2: read A_h1 (8)                           stage A_0(t+2)   MFMA (h1, g1)
+//       ph3: --  (B_g0 fragments kept in registers)  stage B_0(t+2)   MFMA (h1, g0)   + the K-tile's only vmcnt wait
+//     every slot is re-staged >= 2 phases after its last read (WAR) and its DMA has 1.5-2 K-tiles (3-4 us... ~3000 cycles)
+//     to land; the counted wait of ph3 leaves the two newest half-tiles (4 LDS-DMA instructions per wave) in flight and
+//     retires K-tile t+1, which is read from the next phase on, one barrier later (RAW: own vmcnt + a barrier every wave has
+//     passed).  Raw s_barrier throughout: __syncthreads() would drain vmcnt to zero.
+//   * each phase is [fragment reads, stage] barrier [lgkmcnt(0), 16 MFMAs at raised priority] barrier, and the two wave rows
+//     run ONE barrier apart (wr = 1 takes an extra barrier up front, wr = 0 one at the end): the two waves that share a SIMD
+//     (wave w and w + 4) alternate between the matrix segment and the LDS / DMA segment, so the matrix pipe always has a
+//     wave whose operands are already in registers.
+// ------------------------------------------------------------------------------------------------
+template <bool CONV, int EPI, bool DIRECT = false>
+__global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256;
+  constexpr int SLOT = 128 * 128, KBUF = 4 * SLOT;        // 16 KB half-tile slot (128 rows x 128 B); A0 A1 B0 B1 per K-tile
+  // TRANS: C^T accumulator blocks + permuted W rows for the register-direct epilogue (gemm_epilogue_direct)
+  constexpr bool TRANS = DIRECT && !CONV && (EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_GATE);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, nbm * nbn);
+  const int gm_sz = p.group_m;
+  const int per_group = gm_sz * nbn;
+  const int group = bid / per_group, in_group = bid - group * per_group;
+  const int first_m = group * gm_sz;
+  const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+  const int m0 = p.m_begin + (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
+
+  // ---- LDS-DMA sources: this wave stages pieces 2 * wave + {0, 1} (8 local rows x 128 B each) of every half-tile ----
+  // Raw buffer descriptors (A: based at the tile's first row, rows past M read as zeros; convolution: the whole padded input,
+  // rows clamped), one 32-bit byte offset per [half][piece] in VGPRs, the K-tile (or filter tap) offset in an SGPR: staging a
+  // half-tile costs two buffer_load ... lds and no vector ALU.
+  const auto clip = [](long v) { return (int)(v < 0x7fffffffL ? v : 0x7fffffffL); };
+  const long a_row0 = CONV ? 0 : (long)m0 * p.lda;
+  // (the descriptors are rebuilt from these scalars at every use -- loop-invariant SGPR values for the compiler; a
+  //  __amdgpu_buffer_rsrc_t object captured by the nested generic lambdas below does not get through the host pass)
+  const bf16_t* const a_base = p.A + a_row0;
+  const bf16_t* const w_base = p.W + (long)n0 * p.K;
+  const int a_bytes = CONV ? 0x7fffffff : clip(((long)(p.M - m0) * p.lda) * 2);
+  const int w_bytes = clip(((long)(p.N - n0) * p.K) * 2);
+  uint32_t offA[2][2], offW[2][2];                        // [half][piece] byte offsets
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = wave * 16 + i * 8 + (lane >> 3);       // local row of the slot, 0 .. 127
+    const int chunk = (lane & 7) ^ ((lr >> 1) & 7);       // source-side swizzle (the read applies the same key)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int tm = (lr >> 6) * 128 + h * 64 + (lr & 63);
+      if (CONV) {
+        int gm = m0 + tm; gm = gm < p.M ? gm : p.M - 1;
+        const int hw = p.H * p.W_;
+        const int t = gm / hw, rem = gm - t * hw;
+        const int hh = rem / p.W_, w = rem - hh * p.W_;
+        offA[h][i] = (uint32_t)(((((long)t * p.Hp + hh) * p.Wp + w) * p.Cin + chunk * 8) * 2);
+      } else {
+        offA[h][i] = (uint32_t)(((long)tm * p.lda + chunk * 8) * 2);
+      }
+      // local row lr of B_h = wave column (lr >> 5), block (lr >> 4) & 1, MFMA row rho = lr & 15.  TRANS: MFMA row rho of block
+      // jl is column 8 (rho >> 2) + 4 jl + (rho & 3) of the 32, so that a lane's two blocks of a pair are 8 adjacent columns
+      const int c32 = TRANS ? 8 * ((lr & 15) >> 2) + 4 * ((lr >> 4) & 1) + (lr & 3) : (lr & 31);
+      const int tn = (lr >> 5) * 64 + h * 32 + c32;
+      offW[h][i] = (uint32_t)(((long)tn * p.K + chunk * 8) * 2);
+    }
+  }
+  const int nk = p.K / BK;
+  const int cpt = CONV ? p.Cin / BK : 1;
+  auto koff_a = [&](int kt) -> int {                      // byte offset of K-tile kt within an A row
+    if (CONV) {
+      const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+      const int khw = p.kH * p.kW;
+      const int dt = tap / khw, r2 = tap - dt * khw;
+      const int dh = r2 / p.kW, dw = r2 - dh * p.kW;
+      return (int)(((((long)dt * p.Hp + dh) * p.Wp + dw) * p.Cin + c0) * 2);
+    }
+    return kt * (BK * 2);
+  };
+  char* const my_piece = smem + wave * 2048;              // + buffer * KBUF + slot * SLOT (+ 1024 for the second piece)
+  auto stage_a = [&](auto bufc, auto hc, int kt) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(hc)::value * SLOT;
+    stage_pieces<OFF>(a_base, a_bytes, my_piece, offA[decltype(hc)::value][0], offA[decltype(hc)::value][1], koff_a(kt));
+  };
+  auto stage_w = [&](auto bufc, auto gc, int kt) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + (2 + decltype(gc)::value) * SLOT;
+    stage_pieces<OFF>(w_base, w_bytes, my_piece, offW[decltype(gc)::value][0], offW[decltype(gc)::value][1], kt * (BK * 2));
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  // fragment reads: 16x16x32 operand = row (lane & 15), 16-byte chunk ks * 4 + (lane >> 4) of the 128-byte K row; the swizzle
+  // key ((row >> 1) & 7) depends on lane & 15 only (block and wave offsets are multiples of 16 rows), so the blocks of a
+  // subtile are immediate offsets (+2048 B) of one address per k-step
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c = (ks * 4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7);
+    rdA[ks] = (wr * 64 + (lane & 15)) * 128 + (c << 4);
+    rdB[ks] = (wc * 32 + (lane & 15)) * 128 + (c << 4);
+  }
+  bf16x8_t a[4][2], b0[2][2], b1[2][2];
+  auto read_a = [&](auto bufc, auto hc) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(hc)::value * SLOT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[i][ks] = *(const bf16x8_t*)(smem + rdA[ks] + OFF + i * 2048);
+  };
+  auto read_b = [&](auto bufc, auto gc, bf16x8_t (&b)[2][2]) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + (2 + decltype(gc)::value) * SLOT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b[j][ks] = *(const bf16x8_t*)(smem + rdB[ks] + OFF + j * 2048);
+  };
+  const bool wave_live = (n0 + wc * 64 < p.N) && !(p.abl & 8);     // (a wave whose 64 columns lie past N issues no MFMAs)
+  auto mma = [&](auto hc, auto gc, bf16x8_t (&b)[2][2]) {
+    constexpr int H = decltype(hc)::value, G = decltype(gc)::value;
+    // lgkmcnt(0) as the BUILTIN (simm16 0xC07F = vmcnt 63, expcnt 7, lgkmcnt 0): hipcc's own wait-count bookkeeping sees it.  As
+    // inline asm it is invisible to that pass, which then re-waits before the next phase's fragment reads on the path that
+    // skips the MFMAs (a pending ds_read into a register it is about to reuse) -- serialising the B and A reads of ph0.
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_live) {
+#ifndef LD_X_NOPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[H * 4 + i][G * 2 + j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0);
+#ifndef LD_X_NOPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const bool do_bar = !(p.abl & 4);
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_bar) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: K-tile 0 complete, A_0 / B_0 of K-tile 1 in flight ----
+  stage_a(I0{}, I0{}, 0); stage_w(I0{}, I0{}, 0); stage_w(I0{}, I1{}, 0); stage_a(I0{}, I1{}, 0);
+  if (nk > 1) {
+    stage_a(I1{}, I0{}, 1); stage_w(I1{}, I0{}, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  bar();
+  if (wr == 1) bar();                                     // the second wave row runs one barrier behind the first
+
+  const bool do_stage = !(p.abl & 1), do_read = !(p.abl & 2);
+  auto bar1 = [&]() {             // the barrier that ends a load segment
+#ifdef LD_X_WAITB4
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    bar();
+  };
+  auto tile = [&](auto bufc, int kt) {
+    constexpr int B = decltype(bufc)::value;
+    using Bc = std::integral_constant<int, B>;
+    using Nc = std::integral_constant<int, B ^ 1>;
+    // ph0
+    if (do_read) {
+      read_b(Bc{}, I0{}, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(Bc{}, I0{});
+    }
+    if (kt + 1 < nk && do_stage) stage_w(Nc{}, I1{}, kt + 1);
+    bar1(); mma(I0{}, I0{}, b0); bar();
+    // ph1
+    if (do_read) read_b(Bc{}, I1{}, b1);
+    if (kt + 1 < nk && do_stage) stage_a(Nc{}, I1{}, kt + 1);
+    bar1(); mma(I0{}, I1{}, b1); bar();
+    // ph2
+    if (do_read) read_a(Bc{}, I1{});
+    if (kt + 2 < nk && do_stage) stage_a(Bc{}, I0{}, kt + 2);
+    bar1(); mma(I1{}, I1{}, b1); bar();
+    // ph3
+    if (kt + 2 < nk && do_stage) {
+      stage_w(Bc{}, I0{}, kt + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K-tile kt + 1 has landed; A_0 / B_0 of kt + 2 stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar1(); mma(I1{}, I0{}, b0); bar();
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    tile(I0{}, kt);
+    tile(I1{}, kt + 1);
+  }
+  if (kt < nk) tile(I0{}, kt);
+  if (wr == 0) bar();
+  __syncthreads();
+
+  if constexpr (EPI == EPI_QKV) qkv_epilogue16<4>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64);
+  else if constexpr (TRANS) gemm_epilogue_direct<EPI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64);
+  else gemm_epilogue16<4, EPI>(p, acc, 0, smem, wave, lane, m0 + wr * 128, n0 + wc * 64);
+}
+
 // ------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) x fp8 -> fp32 GEMM for the DiT's four large linear layers (BASELINE config 5; never the headline
 // metric, which is bf16).  Same 256x256 tile / 8 waves (2 x 4, 128x64 per wave) / two-stage LDS-DMA structure as
@@ -1091,6 +1410,40 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
 #undef LD_GEMM_LAUNCH
 }
 
+int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
+  constexpr int EPIB = 8 * 32 * CW_STRIDE * 4;
+  constexpr int SMEM0 = 2 * 4 * 128 * 128;                 // 2 K-tile buffers x 4 half-tile slots of 16 KB
+  constexpr int SMEM = SMEM0 > EPIB ? SMEM0 : EPIB;
+  constexpr int SMEM_QKV = (SMEM > 8 * QKV_REGION) ? SMEM : 8 * QKV_REGION;
+  const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
+  dim3 grid(nbm * nbn), block(512);
+  const int epi = pick_epilogue(p);
+  if (epi == EPI_QKV) {
+    LD_REQUIRE(!conv, "ld_gemm_qkv_heads: not a convolution epilogue");
+    return launch_kernel<ld_gemm8p_kernel<false, EPI_QKV>>("ld_gemm_qkv_heads", grid, block, SMEM_QKV, stream, p);
+  }
+  if (conv) {
+    if (epi == EPI_BIAS) return launch_kernel<ld_gemm8p_kernel<true, EPI_BIAS>>("ld_gemm8p", grid, block, SMEM, stream, p);
+    return launch_kernel<ld_gemm8p_kernel<true, EPI_GENERIC>>("ld_gemm8p", grid, block, SMEM, stream, p);
+  }
+  static int direct = -1;      // LD_GEMM_DIRECT=1: register-direct epilogue (C^T accumulators); measured slower than the LDS-staged one
+  if (direct < 0) { const char* e = getenv("LD_GEMM_DIRECT"); direct = e ? atoi(e) : 0; }
+  if (direct) {
+    switch (epi) {
+      case EPI_BIAS: return launch_kernel<ld_gemm8p_kernel<false, EPI_BIAS, true>>("ld_gemm8p", grid, block, SMEM, stream, p);
+      case EPI_GELU: return launch_kernel<ld_gemm8p_kernel<false, EPI_GELU, true>>("ld_gemm8p", grid, block, SMEM, stream, p);
+      case EPI_GATE: return launch_kernel<ld_gemm8p_kernel<false, EPI_GATE, true>>("ld_gemm8p", grid, block, SMEM, stream, p);
+      default: break;
+    }
+  }
+  switch (epi) {
+    case EPI_BIAS: return launch_kernel<ld_gemm8p_kernel<false, EPI_BIAS>>("ld_gemm8p", grid, block, SMEM, stream, p);
+    case EPI_GELU: return launch_kernel<ld_gemm8p_kernel<false, EPI_GELU>>("ld_gemm8p", grid, block, SMEM, stream, p);
+    case EPI_GATE: return launch_kernel<ld_gemm8p_kernel<false, EPI_GATE>>("ld_gemm8p", grid, block, SMEM, stream, p);
+    default: return launch_kernel<ld_gemm8p_kernel<false, EPI_GENERIC>>("ld_gemm8p", grid, block, SMEM, stream, p);
+  }
+}
+
 int launch_w4r(const GemmParams& p, hipStream_t stream) {
   constexpr int SMEM = 2 * (256 + 256) * 64 * 2;   // two 64 KB K-tile slots (the epilogue staging reuses them)
   const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
@@ -1126,14 +1479,18 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     cfg = (tiles256 >= 512 && (conv ? (p.N >= 4096 || p.K >= 4096) : p.K >= 1024)) ? 3 : 1;
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
-  if (cfg != 3 && cfg != 11) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  if (cfg != 3 && cfg != 11 && cfg != 8) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
   // default for the large linear layers: the register-staged 4-wave loop (qkv / 4h / 4h->h GEMMs 3-6 % faster than the
   // 8-wave kernel); the gated-residual epilogue on a short K (DiT proj, K = 1920) hides its operand loads better with 8 waves
   // (round 1 default for the large linear layers: the register-staged 4-wave loop on 32x32x16 MFMAs, LD_GEMM_TILE=11; the
   //  8-wave LDS-DMA kernel on 16x16x32 MFMAs is 3-8 % faster than it on all four DiT shapes: both are bound by the power
   //  governor, and the 16x16x32 form costs less energy per FLOP)
   const bool w4r_default = false;
+  static int use8p = -1, abl = 0;
+  if (use8p < 0) { const char* e = getenv("LD_GEMM_8P"); use8p = e ? atoi(e) : 1; const char* a = getenv("LD_GEMM_ABL"); abl = a ? atoi(a) : 0; }
+  const_cast<GemmParams&>(p).abl = abl;
   auto big = [&](const GemmParams& q) {
+    if ((cfg == 8 || use8p) && cfg != 11) return launch_8p(q, conv, stream);
     if (q.q_out) return launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);      // the fused qkv split lives in the 16x16x32 kernels only
     if ((cfg == 11 || w4r_default) && pp_ok && !conv) return launch_w4r(q, stream);
     return launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);

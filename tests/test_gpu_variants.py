@@ -163,8 +163,12 @@ def _run(snippet, env):
     return float(line.split()[1])
 
 
-@pytest.mark.parametrize("env", [{"LD_GEMM_TILE": "11"}, {"LD_GEMM_TILE": "3", "LD_GEMM_MSPLIT": "0"},
-                                 {"LD_GEMM_TILE": "1"}, {"LD_GEMM_TILE": "3", "LD_GEMM_M16": "0"}, {"LD_GEMM_TILE": "1", "LD_GEMM_M16": "0"}])
+@pytest.mark.parametrize("env", [{"LD_GEMM_TILE": "11"}, {"LD_GEMM_TILE": "3", "LD_GEMM_8P": "0", "LD_GEMM_MSPLIT": "0"},
+                                 {"LD_GEMM_TILE": "1"}, {"LD_GEMM_TILE": "3", "LD_GEMM_8P": "0", "LD_GEMM_M16": "0"},
+                                 {"LD_GEMM_TILE": "1", "LD_GEMM_M16": "0"},
+                                 # the 8-phase loop (round-3 default for large problems) forced onto every size, with and
+                                 # without the M-split tail launch, and with the register-direct epilogue
+                                 {"LD_GEMM_TILE": "8"}, {"LD_GEMM_TILE": "8", "LD_GEMM_MSPLIT": "0"}, {"LD_GEMM_TILE": "8", "LD_GEMM_DIRECT": "1"}])
 def test_gemm_main_loop_variants(cuda, env):
     assert _run(GEMM_SNIPPET, env) < 1e-2
 
