@@ -52,7 +52,6 @@ struct GemmParams {
   int H, W_, Hp, Wp, Cin, kH, kW;   // output H,W; padded input Hp,Wp
   int group_m;                      // tile-raster group height (L2 locality)
   int m_begin;                      // first output row of this launch (rows stay absolute: M is the end row)
-  int abl;                          // LD_GEMM_ABL (timing experiments on the 8-phase loop only; results are wrong when set): 1 no staging, 2 no fragment reads, 4 no barriers, 8 no MFMAs
   // fp8 (e4m3) operands: A and W are byte matrices (lda in bytes), dequantised by per-row / per-output-channel scales
   const float* scale_a;             // [M]
   const float* scale_w;             // [N]
@@ -175,12 +174,17 @@ enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE = 2, EPI_GENERIC = 3, EPI_GELU_MX = 
 
 // stage_block(ic) writes the 32 x 64 fp32 values of 32-row block ic of the wave tile into cw[32][CW_STRIDE] -- the only part
 // that depends on the MFMA shape the accumulators came from (gemm_epilogue: 32x32x16, gemm_epilogue16: 16x16x32).
-template <int MI, int EPI, typename StageFn>
+// hook(): called once, right after the epilogue's FIRST global loads have been issued (bias; gate / residual / control add of
+// the first row block) and before anything waits on them.  The persistent 8-phase kernel issues the next tile's first K-tile
+// there: LDS-DMA and loads retire in order, so anything the epilogue loads after that would wait for the DMA to land.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int MI, int EPI, typename StageFn, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&& stage_block, float* cw, int lane,
-                                                   int row0, int col0w) {
+                                                   int row0, int col0w, Hook&& hook = Hook{}) {
   const int col0 = (lane & 7) * 8;
   const int gn0 = col0w + col0;
   if constexpr (EPI == EPI_GENERIC) {
+    hook();
     const bool vec_ok = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) &&
                         (p.resid == nullptr || (p.ldr & 7) == 0) &&
                         (p.mul == nullptr || (p.ldmul & 7) == 0) &&
@@ -241,6 +245,7 @@ __device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&
           }
         }
       }
+      if constexpr (i == 0) hook();
       stage_block(ic);
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
@@ -326,9 +331,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
 
 // Accumulators of v_mfma_f32_16x16x32_bf16: acc[i][j][r] = C[i * 16 + (lane >> 4) * 4 + r][j * 16 + (lane & 15)], a wave tile of
 // (MI * 32) rows x 64 columns = [2 * MI][4] blocks starting at column block j0.
-template <int MI, int EPI, int NJ>
+template <int MI, int EPI, int NJ, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&acc)[2 * MI][NJ], int j0, char* smem, int wave,
-                                                int lane, int row0, int col0w) {
+                                                int lane, int row0, int col0w, Hook&& hook = Hook{}) {
   float* cw = (float*)smem + wave * (32 * CW_STRIDE);
   auto stage_block = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -340,7 +345,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&a
         for (int r = 0; r < 4; ++r)
           cw[(di * 16 + (lane >> 4) * 4 + r) * CW_STRIDE + j * 16 + (lane & 15)] = acc[2 * i + di][j0 + j][r];
   };
-  gemm_epilogue_core<MI, EPI>(p, stage_block, cw, lane, row0, col0w);
+  gemm_epilogue_core<MI, EPI>(p, stage_block, cw, lane, row0, col0w, hook);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -357,10 +362,10 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&a
 // Rows [Ntok, Npad) of Q / K / V^T are never written: the caller zero-fills those workspaces once.
 // LDS: QKV_REGION bytes per wave (wave-private: only the in-order execution of a wave's own DS instructions orders it).
 constexpr int QKV_REGION = 17408;      // >= 32 * CW_STRIDE * 4 (q/k staging) and 64 * (128 * 2 + 16) (v tile at 128 rows per wave)
-template <int MI>
+template <int MI, typename Hook = NoHook>
 __device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&acc)[2 * MI][4], char* smem, int wave, int lane,
-                                               int row0, int col0w) {
-  if (col0w >= p.N) return;
+                                               int row0, int col0w, Hook&& hook = Hook{}) {
+  if (col0w >= p.N) { hook(); return; }
   const int head = col0w >> 6;
   const int which = head / p.heads, h = head - which * p.heads;       // 0 = q, 1 = k, 2 = v
   char* reg = smem + wave * QKV_REGION;
@@ -382,6 +387,7 @@ __device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&ac
         bv[2 * e] = bf_lo(nbw[e]); bv[2 * e + 1] = bf_hi(nbw[e]);
       }
     }
+    hook();
     auto row_block = [&](auto ic) {
       constexpr int i = decltype(ic)::value;
 #pragma unroll
@@ -437,6 +443,7 @@ __device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&ac
     float bj[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bj[j] = bf2f(p.bias[col0w + j * 16 + (lane & 15)]);
+    hook();
 #pragma unroll
     for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
@@ -717,86 +724,10 @@ __device__ __forceinline__ void stage_pieces(const bf16_t* base, int bytes, char
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + OFF + 1024), 16, o1, ko, 0, 0);
 }
 
-// Register-direct epilogue of the 8-phase kernel (EPI_BIAS / EPI_GELU / EPI_GATE): no LDS round trip.  The kernel runs its MFMAs
-// with the operands SWAPPED (W fragment first), so an accumulator block is C^T: a lane holds four consecutive COLUMNS of one
-// row, and stages its W rows permuted (see ld_gemm8p_kernel) so that the two blocks of a column pair are adjacent:
-//   acc[i][j][r] = C[row0 + 16 i + (lane & 15)][col0w + 32 (j >> 1) + 8 (lane >> 4) + 4 (j & 1) + r]
-// i.e. per (i, column pair) a lane owns 8 consecutive columns = one 16-byte bf16 store, and its epilogue operands (bias, gate,
-// residual, control add) are 16-byte loads at the same place.  Per element the operations and their order are those of
-// gemm_epilogue_core's specialised path: results are bit-identical to the LDS-staged epilogue.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4_t (&acc)[8][4], int lane, int row0, int col0w) {
-  const int r16 = lane & 15, g4 = lane >> 4;
-  int bnd = 0, b0 = 0;
-  if constexpr (EPI == EPI_GATE) {
-    b0 = row0 / p.rows_per_batch;
-    bnd = (b0 + 1) * p.rows_per_batch;
-  }
-  float bias[2][8];
-#pragma unroll
-  for (int pp = 0; pp < 2; ++pp) {
-    const int gn0 = col0w + 32 * pp + 8 * g4;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias[pp][e] = 0.f;
-    if (p.bias && gn0 < p.N) {
-      const u32x4_t bw = *(const u32x4_t*)(p.bias + gn0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bias[pp][2 * e] = bf_lo(bw[e]); bias[pp][2 * e + 1] = bf_hi(bw[e]); }
-    }
-  }
-  // two row blocks x both column pairs per group: the two 64-byte halves of a row's 128-byte line leave back to back
-  auto group = [&](auto i0c) {
-    constexpr int i0 = decltype(i0c)::value;
-    u32x4_t g[2][2], rs[2][2], ad[2][2];
-    if constexpr (EPI == EPI_GATE) {
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-          const int gm = row0 + (i0 + ii) * 16 + r16, gn0 = col0w + 32 * pp + 8 * g4;
-          g[ii][pp] = rs[ii][pp] = ad[ii][pp] = (u32x4_t){0u, 0u, 0u, 0u};
-          if (gm < p.M && gn0 < p.N) {
-            const int b = gm >= bnd ? b0 + 1 : b0;
-            const int rin = gm - b * p.rows_per_batch;
-            g[ii][pp] = *(const u32x4_t*)(p.gate + b * p.gate_bstride + (rin < p.text_len ? p.gate_off_txt : p.gate_off_img) + gn0);
-            rs[ii][pp] = *(const u32x4_t*)((const bf16_t*)p.resid + (long)gm * p.ldr + gn0);
-            if (p.add2) ad[ii][pp] = *(const u32x4_t*)(p.add2 + (long)gm * p.ldadd + gn0);
-          }
-        }
-    }
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int pp = 0; pp < 2; ++pp) {
-        const int gm = row0 + (i0 + ii) * 16 + r16, gn0 = col0w + 32 * pp + 8 * g4;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[i0 + ii][2 * pp][e]; v[4 + e] = acc[i0 + ii][2 * pp + 1][e]; }
-        u32x4_t ow;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ld_f32x2_t x = rbf2((ld_f32x2_t){v[2 * e], v[2 * e + 1]} + (ld_f32x2_t){bias[pp][2 * e], bias[pp][2 * e + 1]});      // bf16 Linear output
-          if constexpr (EPI == EPI_GELU) x = act_gelu_tanh2(x);
-          if constexpr (EPI == EPI_GATE) {
-            x = rbf2(x * unpack_bf16x2(g[ii][pp][e]));
-            x = unpack_bf16x2(rs[ii][pp][e]) + x;
-            if (p.add2) x = rbf2(x) + unpack_bf16x2(ad[ii][pp][e]);
-          }
-          ow[e] = pack_bf16x2(x[0], x[1]);
-        }
-        if (gm < p.M && gn0 < p.N) {
-          if (p.abl & 16) *(u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0) = ow;
-          else __builtin_nontemporal_store(ow, (u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0));
-        }
-      }
-  };
-  group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 2>{});
-  group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 6>{});
-}
-
 // ------------------------------------------------------------------------------------------------
-// 8-phase main loop (round 3; LD_GEMM_TILE=8): the 256x256x64 tile / 8 waves (2 x 4, 128 x 64 per wave) / 16x16x32 MFMAs of
-// ld_gemm_kernel<256,256,2,4,...,M16> with the staging PIPELINED through the K loop instead of issued tile by tile:
+// 8-phase main loop (round 3 default for the 256 x 256 tile; LD_GEMM_8P=0 selects the two-stage loop of ld_gemm_kernel): the
+// 256x256x64 tile / 8 waves (2 x 4, 128 x 64 per wave) / 16x16x32 MFMAs of ld_gemm_kernel<256,256,2,4,...,M16> with the
+// staging PIPELINED through the K loop instead of issued tile by tile:
 //   * LDS = 2 K-tile buffers x 4 half-tile slots of 16 KB: A_h (h = 0, 1) holds, for BOTH wave rows wr, the 64 tile rows
 //     wr * 128 + h * 64 .. + 64 (local row wr * 64 + r); B_g (g = 0, 1) holds, for ALL FOUR wave columns wc, the 32 tile
 //     columns wc * 64 + g * 32 .. + 32 (local row wc * 32 + r).  Which tile row lands in which slot is free -- the LDS-DMA
@@ -809,21 +740,32 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4_
 //       ph1: read B_g1 (4)                           stage A_1(t+1)   MFMA (h0, g1)
 //       ph2: read A_h1 (8)                           stage A_0(t+2)   MFMA (h1, g1)
 //       ph3: --  (B_g0 fragments kept in registers)  stage B_0(t+2)   MFMA (h1, g0)   + the K-tile's only vmcnt wait
-//     every slot is re-staged >= 2 phases after its last read (WAR) and its DMA has 1.5-2 K-tiles (3-4 us... ~3000 cycles)
-//     to land; the counted wait of ph3 leaves the two newest half-tiles (4 LDS-DMA instructions per wave) in flight and
-//     retires K-tile t+1, which is read from the next phase on, one barrier later (RAW: own vmcnt + a barrier every wave has
+//     every slot is re-staged >= 2 phases after its last read (WAR) and its DMA has 1.5-2 K-tiles (~3000 cycles) to land;
+//     the counted wait of ph3 leaves the two newest half-tiles (4 LDS-DMA instructions per wave) in flight and retires
+//     K-tile t+1, which is read from the next phase on, one barrier later (RAW: own vmcnt + a barrier every wave has
 //     passed).  Raw s_barrier throughout: __syncthreads() would drain vmcnt to zero.
-//   * each phase is [fragment reads, stage] barrier [lgkmcnt(0), 16 MFMAs at raised priority] barrier, and the two wave rows
-//     run ONE barrier apart (wr = 1 takes an extra barrier up front, wr = 0 one at the end): the two waves that share a SIMD
-//     (wave w and w + 4) alternate between the matrix segment and the LDS / DMA segment, so the matrix pipe always has a
-//     wave whose operands are already in registers.
+//   * each phase is [fragment reads, stage] barrier [lgkmcnt(0), 16 MFMAs] barrier, and the two wave rows run ONE barrier
+//     apart (wr = 1 takes an extra barrier up front, wr = 0 one at the end): the two waves that share a SIMD (wave w and
+//     w + 4) alternate between the matrix segment and the LDS / DMA segment, so the matrix pipe always has a wave whose
+//     operands are already in registers.
+//   * staging goes through raw buffer descriptors: per-lane byte offsets fixed for the kernel, the K-tile / filter-tap offset
+//     in an SGPR -- two buffer_load ... lds per half-tile and no vector ALU (the flat form cost two 64-bit adds per piece).
+//   * PERSISTENT tiles: the grid is at most one workgroup per CU and a workgroup walks tiles blockIdx.x, + gridDim.x, ... of the
+//     XCD-grouped raster.  The epilogue's LDS staging lives at the END of the 160 KB, clear of K-tile buffer 0, so the first
+//     K-tile of the NEXT tile is requested before the epilogue starts (right after the epilogue's own first loads have been
+//     issued: loads and LDS-DMA retire in order) and lands under it: a tile no longer pays workgroup launch, argument loads and
+//     the first DMA round trip.  (The fused-qkv epilogue needs 136 KB of staging and keeps its prologue after the epilogue.)
+// Measured (tools/gemm_ab.py, profiles/r03_gemm_*): bit-identical outputs; see DESIGN.md section 4.
 // ------------------------------------------------------------------------------------------------
-template <bool CONV, int EPI, bool DIRECT = false>
+constexpr int LD_LDS_TOTAL = 160 * 1024;
+
+template <bool CONV, int EPI>
 __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
   constexpr int BM = 256, BN = 256;
   constexpr int SLOT = 128 * 128, KBUF = 4 * SLOT;        // 16 KB half-tile slot (128 rows x 128 B); A0 A1 B0 B1 per K-tile
-  // TRANS: C^T accumulator blocks + permuted W rows for the register-direct epilogue (gemm_epilogue_direct)
-  constexpr bool TRANS = DIRECT && !CONV && (EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_GATE);
+  constexpr int EPI_BYTES = (EPI == EPI_QKV) ? 8 * QKV_REGION : 8 * 32 * CW_STRIDE * 4;
+  constexpr int EPI_OFF = (LD_LDS_TOTAL - EPI_BYTES) & ~15;      // epilogue staging at the end of the LDS
+  constexpr bool PREFETCH = EPI_OFF >= KBUF;              // K-tile buffer 0 is free while the epilogue runs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -831,50 +773,60 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;
 
   const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, nbm * nbn);
+  const int ntiles = nbm * nbn;
   const int gm_sz = p.group_m;
-  const int per_group = gm_sz * nbn;
-  const int group = bid / per_group, in_group = bid - group * per_group;
-  const int first_m = group * gm_sz;
-  const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
-  const int m0 = p.m_begin + (first_m + in_group % rows_here) * BM, n0 = (in_group / rows_here) * BN;
+  // virtual block id v -> tile origin (XCD-contiguous logical id -> grouped raster, as ld_gemm_kernel).  gridDim.x is a
+  // multiple of 8 whenever a workgroup owns more than one tile, so v % 8 == blockIdx.x % 8: a workgroup's tiles stay on its XCD.
+  auto tile_origin = [&](int v, int& m0, int& n0) {
+    const int bid = xcd_remap(v, ntiles);
+    const int per_group = gm_sz * nbn;
+    const int group = bid / per_group, in_group = bid - group * per_group;
+    const int first_m = group * gm_sz;
+    const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+    m0 = p.m_begin + (first_m + in_group % rows_here) * BM;
+    n0 = (in_group / rows_here) * BN;
+  };
 
   // ---- LDS-DMA sources: this wave stages pieces 2 * wave + {0, 1} (8 local rows x 128 B each) of every half-tile ----
   // Raw buffer descriptors (A: based at the tile's first row, rows past M read as zeros; convolution: the whole padded input,
-  // rows clamped), one 32-bit byte offset per [half][piece] in VGPRs, the K-tile (or filter tap) offset in an SGPR: staging a
-  // half-tile costs two buffer_load ... lds and no vector ALU.
+  // rows clamped), one 32-bit byte offset per [half][piece] in VGPRs, the K-tile (or filter tap) offset in an SGPR.
+  // (The descriptors are rebuilt from their scalars at every use -- loop-invariant SGPR values for the compiler; a
+  //  __amdgpu_buffer_rsrc_t object captured by nested generic lambdas does not get through the host pass.)
   const auto clip = [](long v) { return (int)(v < 0x7fffffffL ? v : 0x7fffffffL); };
-  const long a_row0 = CONV ? 0 : (long)m0 * p.lda;
-  // (the descriptors are rebuilt from these scalars at every use -- loop-invariant SGPR values for the compiler; a
-  //  __amdgpu_buffer_rsrc_t object captured by the nested generic lambdas below does not get through the host pass)
-  const bf16_t* const a_base = p.A + a_row0;
-  const bf16_t* const w_base = p.W + (long)n0 * p.K;
-  const int a_bytes = CONV ? 0x7fffffff : clip(((long)(p.M - m0) * p.lda) * 2);
-  const int w_bytes = clip(((long)(p.N - n0) * p.K) * 2);
+  struct Src { const bf16_t* a; const bf16_t* w; int a_bytes, w_bytes; };
+  auto tile_src = [&](int m0, int n0) {
+    Src s;
+    s.a = p.A + (CONV ? 0 : (long)m0 * p.lda);
+    s.w = p.W + (long)n0 * p.K;
+    s.a_bytes = CONV ? 0x7fffffff : clip(((long)(p.M - m0) * p.lda) * 2);
+    s.w_bytes = clip(((long)(p.N - n0) * p.K) * 2);
+    return s;
+  };
   uint32_t offA[2][2], offW[2][2];                        // [half][piece] byte offsets
+  auto set_offsets = [&](int m0, bool weights) {          // (A offsets depend on the tile only for a convolution)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int lr = wave * 16 + i * 8 + (lane >> 3);       // local row of the slot, 0 .. 127
-    const int chunk = (lane & 7) ^ ((lr >> 1) & 7);       // source-side swizzle (the read applies the same key)
+    for (int i = 0; i < 2; ++i) {
+      const int lr = wave * 16 + i * 8 + (lane >> 3);     // local row of the slot, 0 .. 127
+      const int chunk = (lane & 7) ^ ((lr >> 1) & 7);     // source-side swizzle (the read applies the same key)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int tm = (lr >> 6) * 128 + h * 64 + (lr & 63);
-      if (CONV) {
-        int gm = m0 + tm; gm = gm < p.M ? gm : p.M - 1;
-        const int hw = p.H * p.W_;
-        const int t = gm / hw, rem = gm - t * hw;
-        const int hh = rem / p.W_, w = rem - hh * p.W_;
-        offA[h][i] = (uint32_t)(((((long)t * p.Hp + hh) * p.Wp + w) * p.Cin + chunk * 8) * 2);
-      } else {
-        offA[h][i] = (uint32_t)(((long)tm * p.lda + chunk * 8) * 2);
+      for (int h = 0; h < 2; ++h) {
+        const int tm = (lr >> 6) * 128 + h * 64 + (lr & 63);
+        if (CONV) {
+          int gm = m0 + tm; gm = gm < p.M ? gm : p.M - 1;
+          const int hw = p.H * p.W_;
+          const int t = gm / hw, rem = gm - t * hw;
+          const int hh = rem / p.W_, w = rem - hh * p.W_;
+          offA[h][i] = (uint32_t)(((((long)t * p.Hp + hh) * p.Wp + w) * p.Cin + chunk * 8) * 2);
+        } else {
+          offA[h][i] = (uint32_t)(((long)tm * p.lda + chunk * 8) * 2);
+        }
+        if (weights) {
+          const int tn = (lr >> 5) * 64 + h * 32 + (lr & 31);
+          offW[h][i] = (uint32_t)(((long)tn * p.K + chunk * 8) * 2);
+        }
       }
-      // local row lr of B_h = wave column (lr >> 5), block (lr >> 4) & 1, MFMA row rho = lr & 15.  TRANS: MFMA row rho of block
-      // jl is column 8 (rho >> 2) + 4 jl + (rho & 3) of the 32, so that a lane's two blocks of a pair are 8 adjacent columns
-      const int c32 = TRANS ? 8 * ((lr & 15) >> 2) + 4 * ((lr >> 4) & 1) + (lr & 3) : (lr & 31);
-      const int tn = (lr >> 5) * 64 + h * 32 + c32;
-      offW[h][i] = (uint32_t)(((long)tn * p.K + chunk * 8) * 2);
     }
-  }
+  };
   const int nk = p.K / BK;
   const int cpt = CONV ? p.Cin / BK : 1;
   auto koff_a = [&](int kt) -> int {                      // byte offset of K-tile kt within an A row
@@ -888,22 +840,20 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
     return kt * (BK * 2);
   };
   char* const my_piece = smem + wave * 2048;              // + buffer * KBUF + slot * SLOT (+ 1024 for the second piece)
-  auto stage_a = [&](auto bufc, auto hc, int kt) {
+  Src src;                                                // the tile being computed
+  auto stage_a = [&](const Src& s, auto bufc, auto hc, int kt) {
     constexpr int OFF = decltype(bufc)::value * KBUF + decltype(hc)::value * SLOT;
-    stage_pieces<OFF>(a_base, a_bytes, my_piece, offA[decltype(hc)::value][0], offA[decltype(hc)::value][1], koff_a(kt));
+    stage_pieces<OFF>(s.a, s.a_bytes, my_piece, offA[decltype(hc)::value][0], offA[decltype(hc)::value][1], koff_a(kt));
   };
-  auto stage_w = [&](auto bufc, auto gc, int kt) {
+  auto stage_w = [&](const Src& s, auto bufc, auto gc, int kt) {
     constexpr int OFF = decltype(bufc)::value * KBUF + (2 + decltype(gc)::value) * SLOT;
-    stage_pieces<OFF>(w_base, w_bytes, my_piece, offW[decltype(gc)::value][0], offW[decltype(gc)::value][1], kt * (BK * 2));
+    stage_pieces<OFF>(s.w, s.w_bytes, my_piece, offW[decltype(gc)::value][0], offW[decltype(gc)::value][1], kt * (BK * 2));
   };
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto stage_ktile0 = [&](const Src& s) {
+    stage_a(s, I0{}, I0{}, 0); stage_w(s, I0{}, I0{}, 0); stage_w(s, I0{}, I1{}, 0); stage_a(s, I0{}, I1{}, 0);
+  };
 
   // fragment reads: 16x16x32 operand = row (lane & 15), 16-byte chunk ks * 4 + (lane >> 4) of the 128-byte K row; the swizzle
   // key ((row >> 1) & 7) depends on lane & 15 only (block and wave offsets are multiples of 16 rows), so the blocks of a
@@ -915,6 +865,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
     rdA[ks] = (wr * 64 + (lane & 15)) * 128 + (c << 4);
     rdB[ks] = (wc * 32 + (lane & 15)) * 128 + (c << 4);
   }
+  f32x4_t acc[8][4];
   bf16x8_t a[4][2], b0[2][2], b1[2][2];
   auto read_a = [&](auto bufc, auto hc) {
     constexpr int OFF = decltype(bufc)::value * KBUF + decltype(hc)::value * SLOT;
@@ -930,7 +881,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) b[j][ks] = *(const bf16x8_t*)(smem + rdB[ks] + OFF + j * 2048);
   };
-  const bool wave_live = (n0 + wc * 64 < p.N) && !(p.abl & 8);     // (a wave whose 64 columns lie past N issues no MFMAs)
+  bool wave_live = true;                                  // (a wave whose 64 columns lie past N issues no MFMAs)
   auto mma = [&](auto hc, auto gc, bf16x8_t (&b)[2][2]) {
     constexpr int H = decltype(hc)::value, G = decltype(gc)::value;
     // lgkmcnt(0) as the BUILTIN (simm16 0xC07F = vmcnt 63, expcnt 7, lgkmcnt 0): hipcc's own wait-count bookkeeping sees it.  As
@@ -939,91 +890,106 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_sched_barrier(0);
     if (wave_live) {
-#ifndef LD_X_NOPRIO
       __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[H * 4 + i][G * 2 + j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0)
-                                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0);
-#ifndef LD_X_NOPRIO
+            acc[H * 4 + i][G * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  const bool do_bar = !(p.abl & 4);
   auto bar = [&]() {
     __builtin_amdgcn_sched_barrier(0);
-    if (do_bar) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-
-  // ---- prologue: K-tile 0 complete, A_0 / B_0 of K-tile 1 in flight ----
-  stage_a(I0{}, I0{}, 0); stage_w(I0{}, I0{}, 0); stage_w(I0{}, I1{}, 0); stage_a(I0{}, I1{}, 0);
-  if (nk > 1) {
-    stage_a(I1{}, I0{}, 1); stage_w(I1{}, I0{}, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  bar();
-  if (wr == 1) bar();                                     // the second wave row runs one barrier behind the first
-
-  const bool do_stage = !(p.abl & 1), do_read = !(p.abl & 2);
-  auto bar1 = [&]() {             // the barrier that ends a load segment
-#ifdef LD_X_WAITB4
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
-    bar();
-  };
-  auto tile = [&](auto bufc, int kt) {
+  auto ktile = [&](auto bufc, int kt) {
     constexpr int B = decltype(bufc)::value;
     using Bc = std::integral_constant<int, B>;
     using Nc = std::integral_constant<int, B ^ 1>;
     // ph0
-    if (do_read) {
-      read_b(Bc{}, I0{}, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      read_a(Bc{}, I0{});
-    }
-    if (kt + 1 < nk && do_stage) stage_w(Nc{}, I1{}, kt + 1);
-    bar1(); mma(I0{}, I0{}, b0); bar();
+    read_b(Bc{}, I0{}, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(Bc{}, I0{});
+    if (kt + 1 < nk) stage_w(src, Nc{}, I1{}, kt + 1);
+    bar(); mma(I0{}, I0{}, b0); bar();
     // ph1
-    if (do_read) read_b(Bc{}, I1{}, b1);
-    if (kt + 1 < nk && do_stage) stage_a(Nc{}, I1{}, kt + 1);
-    bar1(); mma(I0{}, I1{}, b1); bar();
+    read_b(Bc{}, I1{}, b1);
+    if (kt + 1 < nk) stage_a(src, Nc{}, I1{}, kt + 1);
+    bar(); mma(I0{}, I1{}, b1); bar();
     // ph2
-    if (do_read) read_a(Bc{}, I1{});
-    if (kt + 2 < nk && do_stage) stage_a(Bc{}, I0{}, kt + 2);
-    bar1(); mma(I1{}, I1{}, b1); bar();
+    read_a(Bc{}, I1{});
+    if (kt + 2 < nk) stage_a(src, Bc{}, I0{}, kt + 2);
+    bar(); mma(I1{}, I1{}, b1); bar();
     // ph3
-    if (kt + 2 < nk && do_stage) {
-      stage_w(Bc{}, I0{}, kt + 2);
+    if (kt + 2 < nk) {
+      stage_w(src, Bc{}, I0{}, kt + 2);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K-tile kt + 1 has landed; A_0 / B_0 of kt + 2 stay in flight
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    bar1(); mma(I1{}, I0{}, b0); bar();
+    bar(); mma(I1{}, I0{}, b0); bar();
   };
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    tile(I0{}, kt);
-    tile(I1{}, kt + 1);
-  }
-  if (kt < nk) tile(I0{}, kt);
-  if (wr == 0) bar();
-  __syncthreads();
 
-  if constexpr (EPI == EPI_QKV) qkv_epilogue16<4>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64);
-  else if constexpr (TRANS) gemm_epilogue_direct<EPI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64);
-  else gemm_epilogue16<4, EPI>(p, acc, 0, smem, wave, lane, m0 + wr * 128, n0 + wc * 64);
+  set_offsets(0, true);
+  bool k0_staged = false;                                 // K-tile 0 of the tile about to start is already on its way
+  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+    int m0, n0;
+    tile_origin(v, m0, n0);
+    src = tile_src(m0, n0);
+    wave_live = n0 + wc * 64 < p.N;
+    if (CONV) set_offsets(m0, false);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: K-tile 0 complete, A_0 / B_0 of K-tile 1 in flight ----
+    if (!k0_staged) stage_ktile0(src);
+    if (nk > 1) {
+      stage_a(src, I1{}, I0{}, 1); stage_w(src, I1{}, I0{}, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    if (wr == 1) bar();                                   // the second wave row runs one barrier behind the first
+
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(I0{}, kt);
+      ktile(I1{}, kt + 1);
+    }
+    if (kt < nk) ktile(I0{}, kt);
+    if (wr == 0) bar();
+    __syncthreads();                                      // every fragment read of this tile has been waited for
+
+    // ---- epilogue, with the next tile's first K-tile requested from inside it ----
+    const int vn = v + gridDim.x;
+    bool hooked = false;
+    Src nsrc = src;
+    k0_staged = false;
+    if (PREFETCH && !CONV && vn < ntiles) {               // (a convolution's next-tile A offsets would need a second register set)
+      int m1, n1;
+      tile_origin(vn, m1, n1);
+      nsrc = tile_src(m1, n1);
+      k0_staged = true;
+    }
+    auto hook = [&]() {
+      if (!hooked && k0_staged) stage_ktile0(nsrc);
+      hooked = true;
+    };
+    if constexpr (EPI == EPI_QKV) qkv_epilogue16<4>(p, acc, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
+    else gemm_epilogue16<4, EPI>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
+    hook();
+    if (vn < ntiles) __syncthreads();                     // the staging region is free again before buffer-1 slots are re-staged
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1411,30 +1377,26 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
 }
 
 int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
-  constexpr int EPIB = 8 * 32 * CW_STRIDE * 4;
-  constexpr int SMEM0 = 2 * 4 * 128 * 128;                 // 2 K-tile buffers x 4 half-tile slots of 16 KB
-  constexpr int SMEM = SMEM0 > EPIB ? SMEM0 : EPIB;
-  constexpr int SMEM_QKV = (SMEM > 8 * QKV_REGION) ? SMEM : 8 * QKV_REGION;
+  constexpr int SMEM = LD_LDS_TOTAL;                       // 2 x 64 KB K-tile buffers; epilogue staging at the end of the 160 KB
   const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
-  dim3 grid(nbm * nbn), block(512);
+  const long ntiles = (long)nbm * nbn;
+  // persistent tiles: one workgroup per CU (LD_GEMM_PERSIST=0: one workgroup per tile)
+  static int persist = -1, ncu = 0;
+  if (persist < 0) {
+    const char* e = getenv("LD_GEMM_PERSIST"); persist = e ? atoi(e) : 1;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0 || (ncu & 7)) ncu = 256;
+  }
+  dim3 grid((unsigned)((persist && ntiles > ncu) ? ncu : ntiles)), block(512);
   const int epi = pick_epilogue(p);
   if (epi == EPI_QKV) {
     LD_REQUIRE(!conv, "ld_gemm_qkv_heads: not a convolution epilogue");
-    return launch_kernel<ld_gemm8p_kernel<false, EPI_QKV>>("ld_gemm_qkv_heads", grid, block, SMEM_QKV, stream, p);
+    return launch_kernel<ld_gemm8p_kernel<false, EPI_QKV>>("ld_gemm_qkv_heads", grid, block, SMEM, stream, p);
   }
   if (conv) {
     if (epi == EPI_BIAS) return launch_kernel<ld_gemm8p_kernel<true, EPI_BIAS>>("ld_gemm8p", grid, block, SMEM, stream, p);
     return launch_kernel<ld_gemm8p_kernel<true, EPI_GENERIC>>("ld_gemm8p", grid, block, SMEM, stream, p);
-  }
-  static int direct = -1;      // LD_GEMM_DIRECT=1: register-direct epilogue (C^T accumulators); measured slower than the LDS-staged one
-  if (direct < 0) { const char* e = getenv("LD_GEMM_DIRECT"); direct = e ? atoi(e) : 0; }
-  if (direct) {
-    switch (epi) {
-      case EPI_BIAS: return launch_kernel<ld_gemm8p_kernel<false, EPI_BIAS, true>>("ld_gemm8p", grid, block, SMEM, stream, p);
-      case EPI_GELU: return launch_kernel<ld_gemm8p_kernel<false, EPI_GELU, true>>("ld_gemm8p", grid, block, SMEM, stream, p);
-      case EPI_GATE: return launch_kernel<ld_gemm8p_kernel<false, EPI_GATE, true>>("ld_gemm8p", grid, block, SMEM, stream, p);
-      default: break;
-    }
   }
   switch (epi) {
     case EPI_BIAS: return launch_kernel<ld_gemm8p_kernel<false, EPI_BIAS>>("ld_gemm8p", grid, block, SMEM, stream, p);
@@ -1486,9 +1448,8 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
   //  8-wave LDS-DMA kernel on 16x16x32 MFMAs is 3-8 % faster than it on all four DiT shapes: both are bound by the power
   //  governor, and the 16x16x32 form costs less energy per FLOP)
   const bool w4r_default = false;
-  static int use8p = -1, abl = 0;
-  if (use8p < 0) { const char* e = getenv("LD_GEMM_8P"); use8p = e ? atoi(e) : 1; const char* a = getenv("LD_GEMM_ABL"); abl = a ? atoi(a) : 0; }
-  const_cast<GemmParams&>(p).abl = abl;
+  static int use8p = -1;
+  if (use8p < 0) { const char* e = getenv("LD_GEMM_8P"); use8p = e ? atoi(e) : 1; }
   auto big = [&](const GemmParams& q) {
     if ((cfg == 8 || use8p) && cfg != 11) return launch_8p(q, conv, stream);
     if (q.q_out) return launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);      // the fused qkv split lives in the 16x16x32 kernels only

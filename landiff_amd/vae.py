@@ -42,6 +42,17 @@ class VAEDecoder:
             else:
                 self.w[k] = _dev(v, device)
         self.cache = {}
+        # Zero-bordered conv-input buffers, one per shape, allocated and zero-filled ONCE: the producing kernels (GroupNorm apply,
+        # upsample, latent placement) rewrite the whole interior on every use and the halo frames are refilled from the cache /
+        # the first frame, so the spatial borders stay zero.  The decoder is a chain -- a buffer's consumer (the conv) is queued
+        # before the next producer of that shape -- so one buffer per shape is enough (stream order is the only hazard).
+        self._padded = {}
+
+    def _padded_buf(self, *shape):
+        buf = self._padded.get(shape)
+        if buf is None:
+            buf = self._padded[shape] = torch.zeros(*shape, device=self.dev, dtype=BF)
+        return buf
 
     # ---- building blocks (x is a plain channels-last [T*H*W, C] tensor) ----------------------
     def _causal_conv(self, xp, name, T, H, W, clear, **epi):
@@ -62,7 +73,7 @@ class VAEDecoder:
         zb = ops.gemm(zq, self.w[name + ".conv_b.conv.weight"], bias=self.w[name + ".conv_b.conv.bias"])
         stats = torch.empty(1, cfg.gn_groups, 2, device=dev, dtype=torch.float64)
         ops.groupnorm_stats(x, stats, 1, T * H * W, C, cfg.gn_groups)
-        out = torch.zeros(T + tpad, H + 2, W + 2, C, device=dev, dtype=BF)
+        out = self._padded_buf(T + tpad, H + 2, W + 2, C)
         ops.groupnorm_apply(x, out, stats, self.w[name + ".norm_layer.weight"], self.w[name + ".norm_layer.bias"],
                             1, T, H, W, C, cfg.gn_groups, zy=zy, zb=zb, zshape=zshape, tpad=tpad, hpad=1, wpad=1,
                             swish=True, eps=cfg.gn_eps)
@@ -82,7 +93,7 @@ class VAEDecoder:
         To = T
         if time_up and T > 1:
             To = 1 + 2 * (T - 1) if T % 2 == 1 else 2 * T
-        xp = torch.zeros(To, 2 * H + 2, 2 * W + 2, C, device=self.dev, dtype=BF)
+        xp = self._padded_buf(To, 2 * H + 2, 2 * W + 2, C)
         ops.place_cl(x, xp, 1, T, H, W, C, C, mode=1, time_up=time_up)
         out = ops.conv_cl(xp, self.w[name + ".conv.weight"], To, 2 * H, 2 * W, bias=self.w[name + ".conv.bias"])
         return out, To, 2 * H, 2 * W
@@ -94,7 +105,7 @@ class VAEDecoder:
         cfg = self.cfg
         zshape = (T, H, W)
         p = "decoder."
-        xp = torch.zeros(T + 2, H + 2, W + 2, ZQ_PAD, device=self.dev, dtype=BF)
+        xp = self._padded_buf(T + 2, H + 2, W + 2, ZQ_PAD)
         ops.place_cl(z_cl, xp, 1, T, H, W, ZQ_PAD, ZQ_PAD, mode=0, tpad=2)
         h = self._causal_conv(xp, p + "conv_in", T, H, W, clear)
         top = h.shape[1]

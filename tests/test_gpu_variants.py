@@ -167,8 +167,8 @@ def _run(snippet, env):
                                  {"LD_GEMM_TILE": "1"}, {"LD_GEMM_TILE": "3", "LD_GEMM_8P": "0", "LD_GEMM_M16": "0"},
                                  {"LD_GEMM_TILE": "1", "LD_GEMM_M16": "0"},
                                  # the 8-phase loop (round-3 default for large problems) forced onto every size, with and
-                                 # without the M-split tail launch, and with the register-direct epilogue
-                                 {"LD_GEMM_TILE": "8"}, {"LD_GEMM_TILE": "8", "LD_GEMM_MSPLIT": "0"}, {"LD_GEMM_TILE": "8", "LD_GEMM_DIRECT": "1"}])
+                                 # without the M-split tail launch, and with one workgroup per tile instead of persistent tiles
+                                 {"LD_GEMM_TILE": "8"}, {"LD_GEMM_TILE": "8", "LD_GEMM_MSPLIT": "0"}, {"LD_GEMM_TILE": "8", "LD_GEMM_PERSIST": "0"}])
 def test_gemm_main_loop_variants(cuda, env):
     assert _run(GEMM_SNIPPET, env) < 1e-2
 
