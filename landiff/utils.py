@@ -7,6 +7,82 @@ import numpy as np
 import torch
 
 
+_LANDIFF_MODEL_PATH = None
+
+
+def verify_md5_checksum(root_dir, checksum_file=None) -> bool:
+    """landiff/utils.py:23-90: every file listed in <repo>/ckpts/CHECKSUM.md5 ("<md5>  ./<relative path>" per line -- the 15
+    files of the released checkpoint tree) exists under root_dir and has that md5.  Stops at the first missing / different
+    file, printing which one; raises FileNotFoundError when the checksum list itself is missing."""
+    import hashlib
+    root_dir = Path(root_dir)
+    checksum_file = Path(checksum_file) if checksum_file else Path(__file__).resolve().parents[1] / "ckpts" / "CHECKSUM.md5"
+    if not checksum_file.exists():
+        raise FileNotFoundError(f"Checksum file does not exist: {checksum_file}")
+    wanted = {}
+    for line in checksum_file.read_text().splitlines():
+        line = line.strip()
+        if line:
+            md5, rel = line.split("  ", 1)
+            wanted[rel[2:] if rel.startswith("./") else rel] = md5
+    for rel, md5 in wanted.items():
+        f = root_dir / rel
+        if not f.exists():
+            print(f"Error: File does not exist: {f}")
+            return False
+        h = hashlib.md5()
+        with open(f, "rb") as fh:
+            for chunk in iter(lambda: fh.read(1 << 20), b""):
+                h.update(chunk)
+        if h.hexdigest() != md5:
+            print(f"Error: File verification failed: {f}\n  Expected MD5: {md5}\n  Actual MD5: {h.hexdigest()}")
+            return False
+    return True
+
+
+def _link_workspace(workspace_path: Path, model_path: Path):
+    """ckpts/LanDiff in the working tree becomes a symlink to where the model really is (landiff/utils.py:150-169), so the
+    relative checkpoint paths of the CLI defaults and the YAML files resolve.  An existing real directory is never touched."""
+    if model_path == workspace_path:
+        return
+    if workspace_path.exists() and not workspace_path.is_symlink():
+        raise FileExistsError(f"Workspace path '{workspace_path}' already exists and is not a symbolic link. Please remove or "
+                              f"rename it manually to create a symbolic link to the model path '{model_path}'.")
+    if workspace_path.is_symlink():
+        workspace_path.unlink()
+    workspace_path.parent.mkdir(parents=True, exist_ok=True)
+    workspace_path.symlink_to(model_path, target_is_directory=True)
+    print(f"Created symbolic link from {workspace_path} to {model_path}")
+
+
+def initialize_landiff_model_path(skip_hash_verification: bool = False) -> Path:
+    """landiff/utils.py:93-217: locate the checkpoint tree -- $LANDIFF_HOME, then <repo>/ckpts/LanDiff -- verify it against
+    ckpts/CHECKSUM.md5 (unless skipped), link it into the working tree; if none is valid, download yinaoxiong/LanDiff from the
+    Hugging Face hub, verify and link that.  The result is cached for the process."""
+    global _LANDIFF_MODEL_PATH
+    if _LANDIFF_MODEL_PATH is not None:
+        return _LANDIFF_MODEL_PATH
+    import os
+    root_dir = Path(__file__).resolve().parents[1]
+    workspace_path = root_dir / "ckpts" / "LanDiff"
+    candidates = ([Path(os.environ["LANDIFF_HOME"])] if os.environ.get("LANDIFF_HOME") else []) + [workspace_path]
+    for model_path in candidates:
+        if model_path.exists() and model_path.is_dir() and (skip_hash_verification or verify_md5_checksum(model_path)):
+            _LANDIFF_MODEL_PATH = model_path
+            _link_workspace(workspace_path, model_path)
+            return model_path
+    print("No valid model path found. Will automatically download LanDiff model from Hugging Face...")
+    from huggingface_hub import snapshot_download
+    download_path = Path(snapshot_download(repo_id="yinaoxiong/LanDiff"))
+    print(f"Model downloaded to {download_path}, performing hash verification...")
+    if not (skip_hash_verification or verify_md5_checksum(download_path)):
+        raise ValueError("Hash verification of the downloaded model failed. Please ensure a stable network connection, "
+                         "or manually download the model and set the LANDIFF_HOME environment variable.")
+    _LANDIFF_MODEL_PATH = download_path
+    _link_workspace(workspace_path, download_path)
+    return download_path
+
+
 def set_seed_for_single_process(seed: int):
     """landiff/utils.py:409-414."""
     torch.manual_seed(seed)

@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("LANDIFF_SKIP_INIT", "1")      # importing `landiff` would otherwise look for / download the released checkpoints
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -286,3 +286,50 @@ def test_cogwrapper_feature_and_video_conditioning(cuda, workdir, monkeypatch):
         bare(VideoTask("v.mp4", "p", 5, mp4=mp4))
     with pytest.raises(KeyError):
         bare(VideoTask("v.mp4", "p", 5))
+
+
+def test_checkpoint_discovery_and_md5_verification(tmp_path, monkeypatch):
+    """initialize_landiff_model_path / verify_md5_checksum (landiff/utils.py:23-217): $LANDIFF_HOME wins, the tree is checked file by
+    file against a checksum list in the format of ckpts/CHECKSUM.md5, a corrupted or missing file fails it, and the shipped
+    list names exactly the 15 files of the released layout."""
+    import hashlib
+    import landiff.utils as lu
+    shipped = [l.split("  ", 1)[1] for l in open(os.path.join(ROOT, "ckpts", "CHECKSUM.md5")).read().splitlines() if l.strip()]
+    assert len(shipped) == 15 and "./llm/model.safetensors" in shipped and "./diffusion/latest" in shipped
+    assert "./CogVideoX-2b-sat/transformer/1000/mp_rank_00_model_states.pt" in shipped and "./CogVideoX-2b-sat/vae/3d-vae.pt" in shipped
+    home = tmp_path / "home"
+    files = {"llm/model.safetensors": b"llm-bytes", "diffusion/latest": b"1", "tokenizer/model.safetensors": b"tok" * 1000}
+    lines = []
+    for rel, data in files.items():
+        (home / rel).parent.mkdir(parents=True, exist_ok=True)
+        (home / rel).write_bytes(data)
+        lines.append(f"{hashlib.md5(data).hexdigest()}  ./{rel}")
+    listing = tmp_path / "CHECKSUM.md5"
+    listing.write_text("\n".join(lines) + "\n")
+    assert hashlib.md5(b"1").hexdigest() == "c4ca4238a0b923820dcc509a6f75849b"          # the shipped list's line for diffusion/latest
+    assert lu.verify_md5_checksum(home, listing)
+    (home / "llm/model.safetensors").write_bytes(b"corrupted")
+    assert not lu.verify_md5_checksum(home, listing)
+    (home / "llm/model.safetensors").unlink()
+    assert not lu.verify_md5_checksum(home, listing)
+    with pytest.raises(FileNotFoundError):
+        lu.verify_md5_checksum(home, tmp_path / "missing.md5")
+    # discovery: LANDIFF_HOME first; hash check skipped -> accepted and cached
+    monkeypatch.setenv("LANDIFF_HOME", str(home))
+    monkeypatch.setattr(lu, "_LANDIFF_MODEL_PATH", None)
+    linked = []
+    monkeypatch.setattr(lu, "_link_workspace", lambda ws, mp: linked.append((ws, mp)))
+    assert lu.initialize_landiff_model_path(skip_hash_verification=True) == home
+    assert linked and linked[0][1] == home and str(linked[0][0]).endswith(os.path.join("ckpts", "LanDiff"))
+    assert lu.initialize_landiff_model_path() == home                                     # cached: no second verification
+    # the link helper refuses to replace a real directory, replaces a stale link
+    monkeypatch.undo()
+    ws = tmp_path / "work" / "ckpts" / "LanDiff"
+    lu._link_workspace(ws, home)
+    assert ws.is_symlink() and os.path.realpath(ws) == os.path.realpath(home)
+    other = tmp_path / "other"; other.mkdir()
+    lu._link_workspace(ws, other)
+    assert os.path.realpath(ws) == os.path.realpath(other)
+    ws.unlink(); ws.mkdir()
+    with pytest.raises(FileExistsError):
+        lu._link_workspace(ws, home)

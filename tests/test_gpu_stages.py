@@ -120,14 +120,21 @@ def test_detokenizer_semantic_condition(cuda, setup):
     g = torch.Generator().manual_seed(1)
     tokens = torch.randint(0, cfg.tok.codebook_size, (cfg.tok.num_latent_tokens,), generator=g)
     orc = DetokenizerOracle(st["tok"], st["ups"], cfg.tok, cfg.ups, torch.bfloat16)
+    orc32 = DetokenizerOracle(st["tok"], st["ups"], cfg.tok, cfg.ups, torch.float32)
     det = Detokenizer(st["tok"], st["ups"], cfg.tok, cfg.ups, cuda)
-    feats_ref = orc.index_to_feature(tokens)                          # [1,T,C,h,w]
+    # the tolerance rule of DESIGN.md section 5: within 2x the bf16 oracle's own distance from the fp32 oracle
+    feats32 = orc32.index_to_feature(tokens)[0]                       # [T,C,h,w]
+    floor_f = rel(orc.index_to_feature(tokens)[0], feats32)
     feats = det.index_to_feature(tokens.to(cuda))                     # [T,h,w,C]
-    assert rel(feats.permute(0, 3, 1, 2), feats_ref[0]) < 4e-2
-    ref = orc.semantic_cond(tokens.reshape(1, 1, -1))[0]             # [T,C,H,W]
+    err_f = rel(feats.permute(0, 3, 1, 2), feats32)
+    assert err_f < max(2 * floor_f, 1e-2), (err_f, floor_f)
+    ref32 = orc32.semantic_cond(tokens.reshape(1, 1, -1))[0]         # [T,C,H,W]
+    floor_c = rel(orc.semantic_cond(tokens.reshape(1, 1, -1))[0], ref32)
     out = det.semantic_condition(tokens.to(cuda))
-    assert out.shape == ref.shape
-    assert rel(out, ref) < 5e-2, rel(out, ref)
+    assert out.shape == ref32.shape
+    err_c = rel(out, ref32)
+    print(f"detokenizer: features err {err_f:.4f} (bf16-oracle floor {floor_f:.4f}), semantic condition err {err_c:.4f} (floor {floor_c:.4f})")
+    assert err_c < max(2 * floor_c, 1e-2), (err_c, floor_c)
 
 
 def test_vae_decode(cuda, setup):
@@ -185,8 +192,15 @@ def test_llm_teacher_forced_logits_and_sampler(cuda, setup):
         fed.append(forced[i] if i in forced else next(it))
     ref_codes, ref_logits = orc.sample(text, num_frames=c.segment_length, guidance_scale=7.5, multinomial_fn=mfn,
                                        teacher_tokens=torch.tensor(fed), return_logits=True)
-    err = (dev_logits - ref_logits).abs().max().item()
-    assert err < 0.35 * max(1.0, ref_logits.abs().max().item() / 10), err
+    # CFG logits (the guidance scale 7.5 amplifies rounding noise by 2 * 7.5 - 1) against the fp32 oracle teacher-forced on the same
+    # history: within 2x the bf16 oracle's own distance from it
+    _, ref32 = LLMOracle(st["llm"], c, torch.float32).sample(text, num_frames=c.segment_length, guidance_scale=7.5, return_logits=True,
+                                                             multinomial_fn=lambda p: torch.multinomial(p, 1), teacher_tokens=torch.tensor(fed))
+    scale = ref32.abs().max().item()
+    floor = (ref_logits - ref32).abs().max().item() / scale
+    err = (dev_logits - ref32).abs().max().item() / scale
+    print(f"tiny LLM teacher-forced CFG logits: err {err:.4f}, bf16-oracle floor {floor:.4f}, |logit|max {scale:.2f}")
+    assert err < max(2 * floor, 2e-2), (err, floor)
     # 3) sampler exactness: given the device's own probabilities the same stream yields the same ids.
     agree = (ref_codes.reshape(-1) == codes.cpu()).float().mean().item()
     assert agree >= 0.8, agree
@@ -264,8 +278,13 @@ def test_llm_first_frame_conditioning(cuda, setup):
                                        multinomial_fn=lambda p: torch.multinomial(p.to(cuda), 1, generator=gen2).cpu(),
                                        teacher_tokens=torch.tensor(fed), first_frame_tokens=first)
     assert dev_logits.shape == ref_logits.shape
-    err = (dev_logits - ref_logits).abs().max().item()
-    assert err < 0.35 * max(1.0, ref_logits.abs().max().item() / 10), err
+    _, ref32 = LLMOracle(st["llm"], c, torch.float32).sample(text, num_frames=c.segment_length, guidance_scale=7.5, return_logits=True,
+                                                             multinomial_fn=lambda p: torch.multinomial(p, 1),
+                                                             teacher_tokens=torch.tensor(fed), first_frame_tokens=first)
+    scale = ref32.abs().max().item()
+    floor = (ref_logits - ref32).abs().max().item() / scale           # 2x-floor rule
+    err = (dev_logits - ref32).abs().max().item() / scale
+    assert err < max(2 * floor, 2e-2), (err, floor)
     assert torch.equal(ref_codes.reshape(-1)[: c.iframe_len], first)
     agree = (ref_codes.reshape(-1) == codes.cpu()).float().mean().item()
     assert agree >= 0.8, agree
