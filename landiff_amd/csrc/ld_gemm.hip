@@ -331,7 +331,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
 
 // Accumulators of v_mfma_f32_16x16x32_bf16: acc[i][j][r] = C[i * 16 + (lane >> 4) * 4 + r][j * 16 + (lane & 15)], a wave tile of
 // (MI * 32) rows x 64 columns = [2 * MI][4] blocks starting at column block j0.
-template <int MI, int EPI, int NJ, typename Hook = NoHook>
+// SWAP: the accumulators came from MFMAs with the operands exchanged (W fragment first), i.e. blocks of C^T:
+//   acc[i][j][r] = C[i * 16 + (lane & 15)][j * 16 + (lane >> 4) * 4 + r]
+// -- a lane's four registers are four consecutive COLUMNS of one row, so staging a block is ONE ds_write_b128 per lane instead of
+// four ds_write_b32 (128 -> 32 LDS store instructions per wave tile; conflict-free: the 8 lanes of a store group are 8 rows,
+// 68 dwords apart).  Same dot products, same results.
+template <int MI, int EPI, int NJ, bool SWAP = false, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&acc)[2 * MI][NJ], int j0, char* smem, int wave,
                                                 int lane, int row0, int col0w, Hook&& hook = Hook{}) {
   float* cw = (float*)smem + wave * (32 * CW_STRIDE);
@@ -340,10 +345,15 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&a
 #pragma unroll
     for (int di = 0; di < 2; ++di)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (SWAP) {
+          *(f32x4_t*)(cw + (di * 16 + (lane & 15)) * CW_STRIDE + j * 16 + (lane >> 4) * 4) = acc[2 * i + di][j0 + j];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cw[(di * 16 + (lane >> 4) * 4 + r) * CW_STRIDE + j * 16 + (lane & 15)] = acc[2 * i + di][j0 + j][r];
+          for (int r = 0; r < 4; ++r)
+            cw[(di * 16 + (lane >> 4) * 4 + r) * CW_STRIDE + j * 16 + (lane & 15)] = acc[2 * i + di][j0 + j][r];
+        }
+      }
   };
   gemm_epilogue_core<MI, EPI>(p, stage_block, cw, lane, row0, col0w, hook);
 }
@@ -766,6 +776,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
   constexpr int EPI_BYTES = (EPI == EPI_QKV) ? 8 * QKV_REGION : 8 * 32 * CW_STRIDE * 4;
   constexpr int EPI_OFF = (LD_LDS_TOTAL - EPI_BYTES) & ~15;      // epilogue staging at the end of the LDS
   constexpr bool PREFETCH = EPI_OFF >= KBUF;              // K-tile buffer 0 is free while the epilogue runs
+  constexpr bool SWAPACC = EPI != EPI_QKV;                // C^T accumulator blocks: 16-byte epilogue staging stores (gemm_epilogue16<SWAP>)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -897,7 +908,8 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[H * 4 + i][G * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0);
+            acc[H * 4 + i][G * 2 + j] = SWAPACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0)
+                                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -986,7 +998,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
       hooked = true;
     };
     if constexpr (EPI == EPI_QKV) qkv_epilogue16<4>(p, acc, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
-    else gemm_epilogue16<4, EPI>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
+    else gemm_epilogue16<4, EPI, 4, SWAPACC>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
     hook();
     if (vn < ntiles) __syncthreads();                     // the staging region is free again before buffer-1 slots are re-staged
   }
@@ -1428,7 +1440,10 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     const char* e = getenv("LD_GEMM_TILE"); forced = e ? atoi(e) : 0;
     const char* g = getenv("LD_GEMM_GROUP_M"); if (g && atoi(g) > 0) group_m = atoi(g);
   }
-  const_cast<GemmParams&>(p).group_m = group_m;
+  // raster group height: 8 x 4 tile patches per XCD (32 resident tiles) for wide outputs; narrow ones (the DiT's N = 1920 GEMMs:
+  // 8 tile columns) do better with 4 rows x all 8 columns -- the whole W panel set stays in the XCD's L2 (ff2 1311 -> 1344 TFLOP/s)
+  static bool group_forced = getenv("LD_GEMM_GROUP_M") != nullptr;
+  const_cast<GemmParams&>(p).group_m = (!group_forced && (p.N + 255) / 256 <= 8) ? 4 : group_m;
   // measured on MI355X (tools/gemm_dit_shapes.py): the 256x256 tile wins once the grid fills the chip twice over
   // (L2->LDS traffic halves); the 128x128 tile (2 workgroups/CU) is for small problems.  A 128x256-tile, two-workgroups-
   // per-CU form of the pipelined loop (epilogue of one workgroup under the main loop of the other) measured 10 % slower
