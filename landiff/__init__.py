@@ -1,7 +1,7 @@
 """Drop-in façade: the reference's import paths (landiff.infer_video, landiff.llm.llm_infer, landiff.diffusion.dif_infer,
 landiff.utils) backed by the MI355X path in ``landiff_amd``.  As in the reference (landiff/__init__.py:14-50) importing the
 package locates the checkpoint tree -- $LANDIFF_HOME, then <repo>/ckpts/LanDiff, else a Hugging Face download --, verifies it
-against ckpts/CHECKSUM.md5 and links it to ckpts/LanDiff; LANDIFF_SKIP_INIT / LANDIFF_SKIP_HASH_CHECK switch that off, and a
+against the md5 list of the released files and links it to ckpts/LanDiff; LANDIFF_SKIP_INIT / LANDIFF_SKIP_HASH_CHECK switch that off, and a
 failure is a warning, not an import error."""
 import os
 

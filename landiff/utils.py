@@ -9,22 +9,47 @@ import torch
 
 _LANDIFF_MODEL_PATH = None
 
+# md5 of the 15 files of the released checkpoint tree (huggingface.co/yinaoxiong/LanDiff) -- the content of the reference's
+# ckpts/CHECKSUM.md5, kept here as data so that a tree can be verified without that file; a ckpts/CHECKSUM.md5 in the working tree
+# (same "<md5>  ./<path>" format) takes precedence.
+RELEASED_MD5 = {
+    "CogVideoX-2b-sat/t5-v1_1-xxl/added_tokens.json": "abe4fe2e108e8ed9432b843545238e53",
+    "CogVideoX-2b-sat/t5-v1_1-xxl/config.json": "874a573dae8c4f440916bab515dc0606",
+    "CogVideoX-2b-sat/t5-v1_1-xxl/model-00001-of-00002.safetensors": "221271c19cda66748bba20871b37d0e9",
+    "CogVideoX-2b-sat/t5-v1_1-xxl/model-00002-of-00002.safetensors": "64fc13b5063d462a73c000b54f1be785",
+    "CogVideoX-2b-sat/t5-v1_1-xxl/model.safetensors.index.json": "ebfc181cf184f4dc9cfffebaeae24d06",
+    "CogVideoX-2b-sat/t5-v1_1-xxl/special_tokens_map.json": "9583322ae544dfbdb0001350ab4c3fd9",
+    "CogVideoX-2b-sat/t5-v1_1-xxl/spiece.model": "9d15ef55d09d5a425ceb63fa31f7cae3",
+    "CogVideoX-2b-sat/t5-v1_1-xxl/tokenizer_config.json": "ae93f8b5fb04998524bc84b3c517b05d",
+    "CogVideoX-2b-sat/transformer/1000/mp_rank_00_model_states.pt": "0c5f18a7b46ab52bae4ffec8a0195e59",
+    "CogVideoX-2b-sat/transformer/latest": "ad865d2f63b9feb2552c220385fbb7e3",
+    "CogVideoX-2b-sat/vae/3d-vae.pt": "e8be4352ababa00ebab19501d2e932bc",
+    "diffusion/1/mp_rank_00_model_states.pt": "f91f8e8eec665115061866529d1ea735",
+    "diffusion/latest": "c4ca4238a0b923820dcc509a6f75849b",
+    "llm/model.safetensors": "db87f2939b0e0a0f4bc74ac8a04ce920",
+    "tokenizer/model.safetensors": "a8b4ed9d4061759ea4314780898767e0",
+}
+
 
 def verify_md5_checksum(root_dir, checksum_file=None) -> bool:
-    """landiff/utils.py:23-90: every file listed in <repo>/ckpts/CHECKSUM.md5 ("<md5>  ./<relative path>" per line -- the 15
-    files of the released checkpoint tree) exists under root_dir and has that md5.  Stops at the first missing / different
-    file, printing which one; raises FileNotFoundError when the checksum list itself is missing."""
+    """landiff/utils.py:23-90: every file of the checksum list ("<md5>  ./<relative path>" per line: <repo>/ckpts/CHECKSUM.md5 if
+    present, else the built-in RELEASED_MD5 table of the 15 released files) exists under root_dir and has that md5.  Stops at the
+    first missing / different file, printing which one; raises FileNotFoundError when a checksum file is named but missing."""
     import hashlib
     root_dir = Path(root_dir)
-    checksum_file = Path(checksum_file) if checksum_file else Path(__file__).resolve().parents[1] / "ckpts" / "CHECKSUM.md5"
-    if not checksum_file.exists():
-        raise FileNotFoundError(f"Checksum file does not exist: {checksum_file}")
-    wanted = {}
-    for line in checksum_file.read_text().splitlines():
-        line = line.strip()
-        if line:
-            md5, rel = line.split("  ", 1)
-            wanted[rel[2:] if rel.startswith("./") else rel] = md5
+    default_file = Path(__file__).resolve().parents[1] / "ckpts" / "CHECKSUM.md5"
+    if checksum_file is None and not default_file.exists():
+        wanted = dict(RELEASED_MD5)
+    else:
+        checksum_file = Path(checksum_file) if checksum_file else default_file
+        if not checksum_file.exists():
+            raise FileNotFoundError(f"Checksum file does not exist: {checksum_file}")
+        wanted = {}
+        for line in checksum_file.read_text().splitlines():
+            line = line.strip()
+            if line:
+                md5, rel = line.split("  ", 1)
+                wanted[rel[2:] if rel.startswith("./") else rel] = md5
     for rel, md5 in wanted.items():
         f = root_dir / rel
         if not f.exists():

@@ -385,3 +385,92 @@ def load_diffusion_config(model_cfg_path: str, infer_cfg_path: str) -> Diffusion
                                force_inference=bool(a.get("force_inference", False)))
     cfg.pipeline().check_diffusion()
     return cfg
+
+
+def reference_yaml_docs(cfg: "PipelineConfig", *, tokenizer_config_str: str = "landiff.tokenizer.tokenizer_cfg.build_tokenizer",
+                        ckpt_prefix: str = "ckpts/LanDiff") -> tuple:
+    """The two YAML documents of the reference's configuration system for a PipelineConfig -- the inverse of
+    load_diffusion_config: (model document, inference document) with the reference's keys and `target:` class paths
+    (cogvideox_2b_control_theia_interpolate_video_vq.yaml / infer_cfgs/2b.yaml).  The files shipped under
+    landiff/diffusion/configs/ are `yaml.safe_dump` of these documents for PipelineConfig.full(); tests write the configs[0] pair
+    the same way.  Only what the inference path reads is emitted (no loss / encoder / regularizer sections)."""
+    import copy
+    d, u, v, sm = cfg.dit, cfg.ups, cfg.vae, cfg.sampler
+    dm = "landiff.diffusion.sgm.modules.diffusionmodules."
+    dv = "landiff.diffusion.dit_video_concat."
+    pos = {"target": dv + "Basic3DPositionEmbeddingMixin",
+           "params": {"text_length": d.text_len, "height_interpolation": d.height_interpolation, "width_interpolation": d.width_interpolation}}
+    patch = {"target": dv + "ImagePatchEmbeddingMixin", "params": {"text_hidden_size": d.text_dim}}
+    targs = {"checkpoint_activations": False, "vocab_size": 1, "max_sequence_length": 64, "layernorm_order": "pre", "skip_init": False,
+             "model_parallel_size": 1, "is_decoder": False}
+    frames = d.pos_frames or d.latent_frames
+    def net(layers):
+        return {"time_embed_dim": d.time_embed_dim, "elementwise_affine": True, "num_frames": v.temporal_compress_times * (frames - 1) + 1,
+                "time_compressed_rate": v.temporal_compress_times, "latent_width": d.latent_w, "latent_height": d.latent_h,
+                "num_layers": layers, "patch_size": d.patch, "in_channels": d.in_channels, "out_channels": d.out_channels,
+                "hidden_size": d.hidden, "adm_in_channels": 256, "num_attention_heads": d.heads, "transformer_args": dict(targs)}
+    control = net(d.layers_control)
+    control["use_semantic_injection_adaln"] = False
+    control["modules"] = {
+        "semantic_condition_config": {"target": "landiff.diffusion.semantic_models.condition.SemanticCond", "params": {
+            "out_dim": u.out_ch, "target_dim": u.target_dim, "feature_type": "video_theia_interpolate", "zero_init_conv_out": True,
+            "semantic_model_config": {"target": "landiff.diffusion.semantic_models.feature_extractor.vq_warp.VideoVQWrap", "params": {
+                "config_str": tokenizer_config_str, "ckpt_path": f"{ckpt_prefix}/tokenizer/model.safetensors", "freeze_model": True,
+                "freeze_encoder": False}},
+            "upsample_model_config": {"target": "landiff.diffusion.semantic_models.modules.vq_gan_blocks.Decoder", "params": {
+                "z_channels": u.z_channels, "resolution": 16, "in_channels": u.ch, "out_ch": u.out_ch, "ch": u.ch, "ch_mult": list(u.ch_mult),
+                "num_res_blocks": u.num_res_blocks, "attn_resolutions": [], "dropout": 0.0, "use_mid_attention": False,
+                "upsample_type": "pixelshuffle"}}}},
+        "pos_embed_config": copy.deepcopy(pos), "patch_embed_config": copy.deepcopy(patch),
+        "adaln_layer_config": {"target": dv + "ControlOutAdaLNMixin", "params": {"qk_ln": True, "use_zero_linears": True}},
+        "final_layer_config": {"target": dv + "EmptyFinalLayerMixin"}}
+    main = net(d.layers_main)
+    main["modules"] = {
+        "pos_embed_config": pos, "patch_embed_config": patch,
+        "adaln_layer_config": {"target": dv + "ControlAdaLNMixin", "params": {"qk_ln": True, "use_semantic_injection_adaln": False,
+                                                                                "control_layers": d.layers_control}},
+        "final_layer_config": {"target": dv + "FinalLayerMixin"}}
+    disc = {"target": dm + "discretizer.ZeroSNRDDPMDiscretization", "params": {"shift_scale": sm.shift_scale}}
+    sampler_cls = {"vpsde_dpmpp2m": "VPSDEDPMPP2MSampler", "ddim": "VideoDDIMSampler"}[sm.sampler]
+    model = {"model": {
+        "scale_factor": v.scale_factor, "disable_first_stage_autocast": True,
+        "pretrain_diffusion_model_ckpt_path": f"{ckpt_prefix}/CogVideoX-2b-sat/transformer/1000/mp_rank_00_model_states.pt", "freeze_dit": True,
+        "denoiser_config": {"target": dm + "denoiser.DiscreteDenoiser", "params": {
+            "num_idx": sm.num_idx, "quantize_c_noise": False, "scaling_config": {"target": dm + "denoiser_scaling.VideoScaling"},
+            "discretization_config": disc}},
+        "control_network_config": {"target": dv + "ControlDiffusionTransformer", "params": control},
+        "network_config": {"target": dv + "DiffusionTransformer", "params": main},
+        "conditioner_config": {"target": "landiff.diffusion.sgm.modules.GeneralConditioner", "params": {"emb_models": [{
+            "is_trainable": False, "input_key": "txt", "ucg_rate": 0.1,
+            "target": "landiff.diffusion.sgm.modules.encoders.modules.FrozenT5Embedder",
+            "params": {"model_dir": f"{ckpt_prefix}/CogVideoX-2b-sat/t5-v1_1-xxl", "max_length": d.text_len}}]}},
+        "first_stage_config": {"target": "landiff.diffusion.vae_modules.autoencoder.VideoAutoencoderInferenceWrapper", "params": {
+            "cp_size": 1, "ckpt_path": f"{ckpt_prefix}/CogVideoX-2b-sat/vae/3d-vae.pt", "ignore_keys": ["loss"],
+            "decoder_config": {"target": "landiff.diffusion.vae_modules.cp_enc_dec.ContextParallelDecoder3D", "params": {
+                "double_z": True, "z_channels": v.z_channels, "resolution": 256, "in_channels": 3, "out_ch": v.out_ch, "ch": v.ch,
+                "ch_mult": list(v.ch_mult), "attn_resolutions": [], "num_res_blocks": v.num_res_blocks, "dropout": 0.0, "gather_norm": False}}}},
+        "sampler_config": {"target": dm + "sampling." + sampler_cls, "params": {
+            "num_steps": sm.num_steps, "verbose": True, "discretization_config": copy.deepcopy(disc),
+            "guider_config": {"target": dm + "guiders.DynamicCFG", "params": {
+                "scale": sm.cfg_scale, "exp": sm.cfg_exp, "num_steps": sm.num_steps}}}}}}
+    infer = {"args": {"image2video": False, "latent_channels": d.in_channels, "mode": "inference", "batch_size": 1,
+                      "sampling_image_size": [8 * d.latent_h, 8 * d.latent_w], "sampling_num_frames": d.latent_frames, "sampling_fps": 8,
+                      "bf16": True, "amp_exclude_key": ["quantizer"], "force_inference": True}}
+    return model, infer
+
+
+def write_reference_yaml(root: str, cfg: "PipelineConfig", **kw) -> tuple:
+    """Writes the two documents at the paths CogModelInferWrapper defaults to, relative to `root`."""
+    import os
+    import yaml
+    model, infer = reference_yaml_docs(cfg, **kw)
+    mp = os.path.join(root, "landiff/diffusion/configs/cogvideox_2b_control_theia_interpolate_video_vq.yaml")
+    ip = os.path.join(root, "landiff/diffusion/configs/infer_cfgs/2b.yaml")
+    os.makedirs(os.path.dirname(ip), exist_ok=True)
+    head = ("# Generated by landiff_amd.config.write_reference_yaml (keys / `target:` names / values of the reference's file of this name,\n"
+            "# inference-relevant sections only).  Read back by landiff_amd.config.load_diffusion_config.\n")
+    for path, doc in ((mp, model), (ip, infer)):
+        with open(path, "w") as f:
+            f.write(head)
+            yaml.safe_dump(doc, f, default_flow_style=None, sort_keys=True, width=150)
+    return mp, ip

@@ -21,6 +21,13 @@ def test_shipped_yaml_files_give_the_full_configuration():
     assert c.image_size == (480, 720) and c.fps == 8 and c.bf16 and c.force_inference
     assert c.t5_dir.endswith("CogVideoX-2b-sat/t5-v1_1-xxl") and c.vae_ckpt.endswith("vae/3d-vae.pt")
     assert c.base_dit_ckpt.endswith("transformer/1000/mp_rank_00_model_states.pt") and c.tokenizer_ckpt.endswith("tokenizer/model.safetensors")
+    # the shipped files are exactly what the generator writes for the full configuration (they cannot drift from the dataclasses)
+    import tempfile
+    from landiff_amd.config import write_reference_yaml
+    with tempfile.TemporaryDirectory() as tmp:
+        mp, ip = write_reference_yaml(tmp, dataclasses.replace(f, dit=dataclasses.replace(f.dit, pos_frames=13)))
+        assert open(mp).read() == open(os.path.join(ROOT, MODEL_YAML)).read()
+        assert open(ip).read() == open(os.path.join(ROOT, INFER_YAML)).read()
     ref = "/root/reference/landiff/diffusion/configs/"
     if os.path.isdir(ref):      # authoring container only: the reference's own files parse to the same configuration
         r = load_diffusion_config(ref + "cogvideox_2b_control_theia_interpolate_video_vq.yaml", ref + "infer_cfgs/2b.yaml")
@@ -290,13 +297,13 @@ def test_cogwrapper_feature_and_video_conditioning(cuda, workdir, monkeypatch):
 
 def test_checkpoint_discovery_and_md5_verification(tmp_path, monkeypatch):
     """initialize_landiff_model_path / verify_md5_checksum (landiff/utils.py:23-217): $LANDIFF_HOME wins, the tree is checked file by
-    file against a checksum list in the format of ckpts/CHECKSUM.md5, a corrupted or missing file fails it, and the shipped
-    list names exactly the 15 files of the released layout."""
+    file against a checksum list in the format of ckpts/CHECKSUM.md5, a corrupted or missing file fails it, and the built-in
+    table names exactly the 15 files of the released layout."""
     import hashlib
     import landiff.utils as lu
-    shipped = [l.split("  ", 1)[1] for l in open(os.path.join(ROOT, "ckpts", "CHECKSUM.md5")).read().splitlines() if l.strip()]
-    assert len(shipped) == 15 and "./llm/model.safetensors" in shipped and "./diffusion/latest" in shipped
-    assert "./CogVideoX-2b-sat/transformer/1000/mp_rank_00_model_states.pt" in shipped and "./CogVideoX-2b-sat/vae/3d-vae.pt" in shipped
+    shipped = lu.RELEASED_MD5
+    assert len(shipped) == 15 and "llm/model.safetensors" in shipped and shipped["diffusion/latest"] == hashlib.md5(b"1").hexdigest()
+    assert "CogVideoX-2b-sat/transformer/1000/mp_rank_00_model_states.pt" in shipped and "CogVideoX-2b-sat/vae/3d-vae.pt" in shipped
     home = tmp_path / "home"
     files = {"llm/model.safetensors": b"llm-bytes", "diffusion/latest": b"1", "tokenizer/model.safetensors": b"tok" * 1000}
     lines = []
