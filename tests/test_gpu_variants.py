@@ -17,7 +17,8 @@ from landiff_amd import ops
 torch.manual_seed(0)
 dev = "cuda"
 worst = 0.0
-for (M, N, K) in [(256, 256, 128), (300, 200, 256), (1000, 1920, 384), (5000, 512, 1920), (70000, 256, 128)]:
+# (the last three: more tiles than CUs -> persistent workgroups walk several tiles, with 1, 2 and 3 (odd) K-tiles per tile)
+for (M, N, K) in [(256, 256, 128), (300, 200, 256), (1000, 1920, 384), (5000, 512, 1920), (70000, 256, 128), (70000, 512, 64), (66000, 264, 192)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
     a[:, 0] += torch.arange(M, device=dev).to(torch.bfloat16) * 0.01          # transposition-detecting
