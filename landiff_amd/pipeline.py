@@ -241,8 +241,9 @@ class LanDiffPipeline:
             parts = []
             for sidx in range(f0 // T, (f1 - 1) // T + 1):
                 if sidx not in sem_seg:
+                    tok = seg_tokens(sidx)                 # (overlapped decode: blocks until the segment's last token is queued)
                     t1 = time.perf_counter()
-                    sem_seg[sidx] = self.detok.semantic_condition(seg_tokens(sidx))
+                    sem_seg[sidx] = self.detok.semantic_condition(tok)
                     self._t("detokenize", t1)
                 lo, hi = max(f0, sidx * T) - sidx * T, min(f1, (sidx + 1) * T) - sidx * T
                 parts.append(sem_seg[sidx][lo:hi])
