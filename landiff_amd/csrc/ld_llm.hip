@@ -308,7 +308,9 @@ __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbat
   const int er = tid / B, eb = tid - er * B;          // this thread's epilogue output within a batch: (row er, batch row eb)
 
   u32x4_t wn[R][J], w2n[GATED ? R : 1][J];
-  float e_bias_n = 0.f, e_res_n = 0.f;
+  // epilogue operands are kept as loaded (raw bits) until the epilogue converts them: a conversion here would make wave 0 wait
+  // for the batch it has just requested (loads return in order) before it computes the current one
+  uint32_t e_bias_n = 0u, e_res_n = 0u;
   // request one batch (R consecutive weight rows + the epilogue operands of its outputs)
   auto request = [&](int batch) {
     const int n0 = batch * R;
@@ -328,23 +330,31 @@ __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbat
     }
     const int en = n0 + er;
     if (tid < R * B && en < p.N) {
-      if (p.bias) e_bias_n = bf2f(p.bias[en]);
-      if (p.resid) e_res_n = p.out_f32 ? ((const float*)p.resid)[eb * p.ldr + en] : bf2f(((const bf16_t*)p.resid)[eb * p.ldr + en]);
+      if (p.bias) e_bias_n = p.bias[en];
+      if (p.resid) e_res_n = p.out_f32 ? ((const uint32_t*)p.resid)[eb * p.ldr + en] : (uint32_t)((const bf16_t*)p.resid)[eb * p.ldr + en];
     }
   };
 
   // ---- x (L2) and the RMSNorm gains first, then the first batch of weight rows (HBM): all in flight together ----
   u32x4_t xq[B][J];
   f32x4_t g0[NORM ? J : 1], g1[NORM ? J : 1];
+  // bounds-checked buffer loads (chunks past K read as zero): no branch and no zero-initialised destination -- with predicated
+  // global loads the register allocator placed a v_mov behind every x load and the wave waited for each load in turn BEFORE the
+  // first weight row had been requested (one L2 round trip per launch, six in the K = 11008 form)
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int c = j * 256 + tid;
+  for (int b = 0; b < B; ++b) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.x + b * p.ldx), 0, p.K * 2, 0x00020000);
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      xq[b][j] = (u32x4_t){0u, 0u, 0u, 0u};
-      if (c < nchunk) xq[b][j] = *(const u32x4_t*)((const bf16_t*)p.x + b * p.ldx + c * 8);
+    for (int j = 0; j < J; ++j) xq[b][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (j * 256 + tid) * 16, 0, 0);
+  }
+  if (NORM) {
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.norm_w, 0, p.K * 4, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rg, (j * 256 + tid) * 32, 0, 0);
+      const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rg, (j * 256 + tid) * 32 + 16, 0, 0);
+      g0[j] = __builtin_bit_cast(f32x4_t, a); g1[j] = __builtin_bit_cast(f32x4_t, b);
     }
-    if (NORM && c < nchunk) { g0[j] = *(const f32x4_t*)(p.norm_w + c * 8); g1[j] = *(const f32x4_t*)(p.norm_w + c * 8 + 4); }
   }
   int batch = blockIdx.x;
   request(batch);
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbat
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int j = 0; j < J; ++j) { w[r][j] = wn[r][j]; if (GATED) w2[r][j] = w2n[r][j]; }
-    const float e_bias = e_bias_n, e_res = e_res_n;
+    const uint32_t e_bias_raw = e_bias_n, e_res_raw = e_res_n;
     if (batch + (int)gridDim.x < nbatch) request(batch + gridDim.x);
 
     float v[V];
@@ -411,6 +421,7 @@ __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbat
     if (tid < R * B && en < p.N) {
       const float(&rd)[4][V] = red[par];
       float a = rd[0][tid] + rd[1][tid] + rd[2][tid] + rd[3][tid];
+      const float e_bias = bf2f((bf16_t)e_bias_raw), e_res = p.out_f32 ? __uint_as_float(e_res_raw) : bf2f((bf16_t)e_res_raw);
       if (p.bias) a += e_bias;
       a = rbf(a);                                        // bf16 Linear output
       if (p.act) a = rbf(apply_act(p.act, a));
