@@ -21,7 +21,7 @@ extern "C" {
 /* Bumped whenever a signature changes or an entry point is added / removed (2: ld_groupnorm_stats took its `partials`
  * argument, ld_gemm_qkv_heads / ld_llm_sample_advance / ld_groupnorm_stats_blocks / ld_attn_last_kernel were added).  A caller
  * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does). */
-#define LD_ABI_VERSION 2
+#define LD_ABI_VERSION 3
 
 int ld_version(void);
 const char* ld_last_error(void);
@@ -187,7 +187,9 @@ int ld_llm_rope_append(const void* qkv, const float* cos_t, const float* sin_t, 
 
 /* Attention of query j (position *pos + j) over keys [0, *pos + j] (transformer_blocks.py:166-186):
  * bf16 scores, bf16(score / sqrt(128)), fp32 softmax -> bf16 p, bf16 output [B][m][H][128].
- * m == 1 with nsplit > 1 uses the key-split path (workspace: B*H*nsplit*130 floats, caller-owned; p kept fp32); there
+ * m == 1 with nsplit > 1 uses the key-split path (workspace: B*H*(nsplit*130 + 1) 4-byte words, caller-owned; the last B*H
+ * words are arrival counters that must be ZERO before the first call -- the launch leaves them zero: the last split of a
+ * (batch row, head) to arrive merges the partial results, no second launch; p kept fp32); there
  * qkv_fused ([B][3][H][128], q may be NULL) makes the kernel do apply_rope and the KV append of the new token itself. */
 int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
                    int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit,
@@ -201,7 +203,8 @@ int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, cons
  * ~150 launches of a step are then bound by the GPU (~1.2 ms) and not by the host language's per-call overhead.
  * emb_table == NULL: x already holds the embedding rows of the token (written by ld_llm_sample_advance).
  * All step state (*token, *pos) is read on the device; buffers are caller-owned: x/att [B][hidden], qkv [B][3*hidden],
- * gate [B][mlp] bf16, attn_ws B*heads*nsplit*130 floats, lnf_out [B][hidden] fp32, logits [B][vocab] fp32. */
+ * gate [B][mlp] bf16, attn_ws B*heads*(nsplit*130 + 1) words (see ld_llm_kv_attn: the last B*heads zero), lnf_out [B][hidden] fp32,
+ * logits [B][vocab] fp32. */
 typedef struct ld_llm_layer {
   const void* wqkv; const void* wo; const void* w1; const void* w3; const void* w2;   /* bf16 [3h][h] [h][h] [mlp][h] [mlp][h] [h][mlp] */
   const float* n0; const float* n1;                                                    /* RMSNorm gains, fp32 [h] */
@@ -212,6 +215,25 @@ int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, const fl
                           const float* cos_t, const float* sin_t, const float* lnf_w, const float* lnf_b, float* lnf_out,
                           const float* head_w, float* logits, int64_t B, int64_t hidden, int64_t heads, int64_t mlp,
                           int64_t vocab, int64_t Lmax, int64_t nsplit, float rms_eps, float ln_eps, void* stream);
+
+/* The same step with all blocks in ONE persistent launch (ld_llm_fused.hip): identical bits, ~one launch instead of 144.
+ * layers_dev: the ld_llm_layer table in DEVICE memory.  ctl: LD_LLM_FUSED_CTL_WORDS 32-bit words of device memory owned by
+ * the caller, zeroed before the first step of a decode (word 0: steps done, word 1: error flag -- non-zero after a grid
+ * barrier timed out; every later launch then returns without touching anything; words 32..: arrival counters).  The launch
+ * needs the GPU's CUs to itself (its workgroups wait for each other): do not run it concurrently with other streams' kernels.
+ * LD_ERR_UNSUPPORTED (nothing launched) unless B == 2, head_dim 128, hidden <= 2048, mlp <= 12288, nsplit >= 2 and at most
+ * 256 keys per split -- use ld_llm_decode_forward then.  Replaces transformer_blocks.py:128-236 / transformer.py:91-119. */
+#define LD_LLM_FUSED_CTL_WORDS 512
+int ld_llm_decode_blocks_fused(const ld_llm_layer* layers_dev, int64_t n_layers, const int32_t* pos, void* x, void* qkv, void* att,
+                               void* gate, float* attn_ws, const float* cos_t, const float* sin_t, int64_t B, int64_t hidden,
+                               int64_t heads, int64_t mlp, int64_t Lmax, int64_t nsplit, float rms_eps, uint32_t* ctl, void* stream);
+/* embedding (optional) -> ld_llm_decode_blocks_fused -> final LayerNorm -> fp32 head: the drop-in form of ld_llm_decode_forward */
+int ld_llm_decode_forward_fused(const ld_llm_layer* layers_dev, int64_t n_layers, const float* emb_table, const int64_t* token,
+                                const int32_t* pos, void* x, void* qkv, void* att, void* gate, float* attn_ws,
+                                const float* cos_t, const float* sin_t, const float* lnf_w, const float* lnf_b, float* lnf_out,
+                                const float* head_w, float* logits, int64_t B, int64_t hidden, int64_t heads, int64_t mlp,
+                                int64_t vocab, int64_t Lmax, int64_t nsplit, float rms_eps, float ln_eps, uint32_t* ctl,
+                                void* stream);
 
 /* nn.Embedding lookup of *token (fp32 table [V][D]) -> bf16 features [B][D] (landiff/llm/modules/tokenizer.py:10-55). */
 int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B, int64_t D, void* stream);

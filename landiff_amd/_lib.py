@@ -44,7 +44,7 @@ class LlmLayer(Structure):
 
 
 _lib = None
-ABI_VERSION = 2          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
+ABI_VERSION = 3          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
 
 I64 = c_int64
 I32 = c_int32
@@ -75,6 +75,9 @@ SIGNATURES: dict[str, list] = {
     "ld_vq_nearest": [P, I64, P, P, I64, I64, I64, P],
     "ld_llm_decode_forward": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
                               c_float, c_float, P],
+    "ld_llm_decode_blocks_fused": [P, I64, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_float, P, P],
+    "ld_llm_decode_forward_fused": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
+                                    c_float, c_float, P, P],
     "ld_llm_logits_to_probs": [P, P, P, I64, I32, c_float, c_float, P, P, I64, I32, c_float, P],
     "ld_llm_decode_advance": [P, P, P, P, P, P, P],
     "ld_llm_sample_advance": [P, P, P, I64, I32, c_float, c_float, P, P, I64, I32, c_float, P, P, P, P, P, P, P, P, I64, I64, P],

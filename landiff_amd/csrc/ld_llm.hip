@@ -12,6 +12,7 @@
 // not shared across waves), one wave64 per output row, activations (<= 4 x K bf16) stay in L1/L2.
 // All per-step scalars (position, token) live in device memory so the whole step is graph-capturable.
 #include "ld_common.h"
+#include "ld_llm_dev.h"
 #include <stdlib.h>
 #include "../../include/landiff_hip.h"
 
@@ -271,33 +272,6 @@ __global__ __launch_bounds__(256) void ld_gemv_kernel(GemvParams p) {
 // sums are reduced across the wave with a transposing butterfly (V + 6 - log2 V shuffles for V values instead of
 // 6 V) and across the 4 waves through LDS.
 // ---------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-
-__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
-}
-
-// Sum V (power of two, <= 64) per-lane values over the 64 lanes; afterwards lane L holds the total of value
-// L >> (6 - log2 V) (every lane of that group holds the same number).
-template <int V, int N = V, int O = 32>
-__device__ __forceinline__ void wave_sum_multi(float (&v)[V], int lane) {
-  if constexpr (N > 1) {
-    const bool up = (lane & O) != 0;
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) {
-      const float keep = up ? v[i + N / 2] : v[i];
-      const float send = up ? v[i] : v[i + N / 2];
-      v[i] = keep + __shfl_xor(send, O, 64);
-    }
-    wave_sum_multi<V, N / 2, O / 2>(v, lane);
-  } else if constexpr (O > 0) {
-    v[0] += __shfl_xor(v[0], O, 64);
-    wave_sum_multi<V, 1, O / 2>(v, lane);
-  }
-}
-constexpr int ceil_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-constexpr int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-
 template <int B, int R, int J, bool GATED, bool NORM>
 __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbatch) {
   constexpr int NV = R * B * (GATED ? 2 : 1), V = ceil_pow2(NV), LOGV = ilog2(V);
@@ -363,12 +337,7 @@ __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbat
   if (NORM) {
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-      float ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float lo = bf_lo(xq[b][j][e]), hi = bf_hi(xq[b][j][e]); ss += lo * lo + hi * hi; }
-      ss = wave_sum(ss);
+      const float ss = wave_sum(chunks_sumsq<J>(xq[b]));
       if (lane == 0) ssq[wave][b] = ss;
     }
     __syncthreads();
@@ -630,11 +599,19 @@ __global__ __launch_bounds__(256) void ld_kv_attn_kernel(const bf16_t* q, const 
 // If qkv != nullptr the kernel also does apply_rope + the KV append of the current token itself (q is then ignored):
 // every workgroup rotates q on the fly; the workgroup whose key range holds position *pos rotates/stores the new k
 // and v into the cache before using them.
-constexpr int KV_MAXIT = 16;     // trips of 16 keys per workgroup: a split covers at most 256 keys
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The merge of the splits rides in the same launch: every workgroup writes its partial result device-coherently (sc1), drains
+// the stores and arrives on the (batch row, head)'s counter; the LAST one to arrive reads all partial results (sc1 loads),
+// writes the attention output and leaves the counter at zero for the next launch.  Nobody waits for anybody (no co-residency
+// requirement); one launch and one ~5 us dependent kernel per block less than split + combine.
 __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, const bf16_t* qkv, const float* cos_t,
                                                                const float* sin_t, bf16_t* kc, bf16_t* vc,
-                                                               const int* pos_ptr, float* ws, int B, int H, int Lmax, int nsplit) {
-  extern __shared__ float sc[];       // [chunk] scores + reductions
+                                                               const int* pos_ptr, float* ws, unsigned* counters, bf16_t* out,
+                                                               int B, int H, int Lmax, int nsplit) {
+  extern __shared__ float sc[];       // [chunk] (unused since the scores live in registers) + reductions
+  __shared__ int is_last;
   const int D = 128;
   const int bh = blockIdx.x, sp = blockIdx.y;
   const int b = bh / H, h = bh - b * H;
@@ -647,131 +624,43 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
   float* out_ws = ws + ((long)bh * nsplit + sp) * (D + 2);
   float* red = sc + ((Lmax + nsplit - 1) / nsplit + 16);
   if (n == 0) {
-    if (tid < D) out_ws[2 + tid] = 0.f;
-    if (tid == 0) { out_ws[0] = -3.0e38f; out_ws[1] = 0.f; }
-    return;
-  }
-  // Request order = dependency order: the new token's q/k/v + rotation factors first (short, L2), then this wave's K
-  // rows AND V rows (4 keys per trip, <= KV_MAXIT trips) all at once -- one exposed HBM latency per launch, and the RoPE
-  // arithmetic runs underneath it.  The key being appended this step is taken from qkv directly (its cache slot is
-  // written for later steps but not read back here), so the prologue needs no barrier.
-  float qreg[8];
-  u32x4_t a_q = (u32x4_t){0u, 0u, 0u, 0u}, a_k = a_q, a_v = a_q;
-  float cs[4], sn[4];
-  const int pos = L - 1;
-  if (qkv) {
-    const bf16_t* src = qkv + ((long)b * 3 * H + h) * D;      // [B][3][H][128]: q at +0, k at +H*D, v at +2*H*D
-    a_q = *(const u32x4_t*)(src + sub * 8);
-    a_k = *(const u32x4_t*)(src + (long)H * D + sub * 8);
-    a_v = *(const u32x4_t*)(src + 2L * H * D + sub * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { cs[e] = cos_t[pos * 64 + sub * 4 + e]; sn[e] = sin_t[pos * 64 + sub * 4 + e]; }
+    if (tid < D) st_agent(out_ws + 2 + tid, 0.f);
+    if (tid == 0) { st_agent(out_ws, -3.0e38f); st_agent(out_ws + 1, 0.f); }
   } else {
-    a_q = *(const u32x4_t*)(q + ((long)b * H + h) * D + sub * 8);
-  }
-  u32x4_t kr[KV_MAXIT], vr[KV_MAXIT];
+    // Request order = dependency order: the new token's q/k/v + rotation factors first (short, L2), then this wave's K
+    // rows AND V rows (4 keys per trip, <= KV_MAXIT trips) all at once -- one exposed HBM latency per launch, and the RoPE
+    // arithmetic runs underneath it.  The key being appended this step is taken from qkv directly (its cache slot is
+    // written for later steps but not read back here), so the prologue needs no barrier.
+    u32x4_t a_q = (u32x4_t){0u, 0u, 0u, 0u}, a_k = a_q, a_v = a_q;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, sn[4] = {0.f, 0.f, 0.f, 0.f};
+    const int pos = L - 1;
+    if (qkv) {
+      const bf16_t* src = qkv + ((long)b * 3 * H + h) * D;      // [B][3][H][128]: q at +0, k at +H*D, v at +2*H*D
+      a_q = *(const u32x4_t*)(src + sub * 8);
+      a_k = *(const u32x4_t*)(src + (long)H * D + sub * 8);
+      a_v = *(const u32x4_t*)(src + 2L * H * D + sub * 8);
 #pragma unroll
-  for (int it = 0; it < KV_MAXIT; ++it) {
-    const int kk = wave * 4 + it * 16 + kq;
-    kr[it] = (u32x4_t){0u, 0u, 0u, 0u}; vr[it] = (u32x4_t){0u, 0u, 0u, 0u};
-    if (it * 16 >= n) continue;
-    if (kk < n) {
-      const long off = (((long)b * Lmax + k_begin + kk) * H + h) * D + sub * 8;
-      kr[it] = __builtin_nontemporal_load((const u32x4_t*)(kc + off));
-      vr[it] = __builtin_nontemporal_load((const u32x4_t*)(vc + off));
+      for (int e = 0; e < 4; ++e) { cs[e] = cos_t[pos * 64 + sub * 4 + e]; sn[e] = sin_t[pos * 64 + sub * 4 + e]; }
+    } else {
+      a_q = *(const u32x4_t*)(q + ((long)b * H + h) * D + sub * 8);
     }
+    KvRows rows;
+    kv_rows_request(rows, kc, vc, (long)b * Lmax + k_begin, H, h, n, wave, kq, sub);
+    kv_attn_split_core(rows, a_q, a_k, a_v, cs, sn, qkv != nullptr, kc, vc, (long)b * Lmax + pos, H, h, pos - k_begin, n, true,
+                       out_ws, red, red + 8, tid, lane, wave, [](float* p, float v) { st_agent(p, v); });
   }
-  if (qkv) {
-    u32x4_t knew;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float qa = bf_lo(a_q[e]), qb = bf_hi(a_q[e]);
-      qreg[2 * e] = rbf(qa * cs[e] - qb * sn[e]);
-      qreg[2 * e + 1] = rbf(qa * sn[e] + qb * cs[e]);
-      const float ka = bf_lo(a_k[e]), kb = bf_hi(a_k[e]);
-      knew[e] = pack_bf16x2(ka * cs[e] - kb * sn[e], ka * sn[e] + kb * cs[e]);
-    }
-    const int pk = pos - k_begin;                              // slot of the new key inside this split, if it is here
-    if (pk >= 0 && pk < n) {
-      if (wave == 0 && kq == 0) {                              // append for the following steps
-        const long co = (((long)b * Lmax + pos) * H + h) * D + sub * 8;
-        *(u32x4_t*)(kc + co) = knew;
-        *(u32x4_t*)(vc + co) = a_v;
-      }
-#pragma unroll
-      for (int it = 0; it < KV_MAXIT; ++it) {
-        if (wave * 4 + it * 16 + kq == pk) { kr[it] = knew; vr[it] = a_v; }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { qreg[2 * e] = bf_lo(a_q[e]); qreg[2 * e + 1] = bf_hi(a_q[e]); }
-  }
-  const float inv_sqrt_d = 0.08838834764831845f;
-  float lmax = -3.0e38f;
-  float sreg[KV_MAXIT];
-#pragma unroll
-  for (int it = 0; it < KV_MAXIT; ++it) {
-    const int kk = wave * 4 + it * 16 + kq;
-    sreg[it] = -3.0e38f;
-    if (it * 16 >= n) continue;                       // workgroup-uniform: trips past this split's keys cost nothing
-    float d = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { d = fmaf(qreg[2 * e], bf_lo(kr[it][e]), d); d = fmaf(qreg[2 * e + 1], bf_hi(kr[it][e]), d); }
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-    if (kk < n) {
-      sreg[it] = rbf(rbf(d) * inv_sqrt_d);
-      lmax = fmaxf(lmax, sreg[it]);
-    }
-  }
-  lmax = wave_max(lmax);
-  if (lane == 0) red[wave] = lmax;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's part of the partial result is at the coherence point
   __syncthreads();
-  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float acc[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  float lsum = 0.f;
-#pragma unroll
-  for (int it = 0; it < KV_MAXIT; ++it) {
-    const int kk = wave * 4 + it * 16 + kq;
-    if (it * 16 >= n) continue;
-    if (kk < n) {
-      const float pk = __expf(sreg[it] - mx);
-      if (sub == 0) lsum += pk;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { acc[2 * e] = fmaf(pk, bf_lo(vr[it][e]), acc[2 * e]); acc[2 * e + 1] = fmaf(pk, bf_hi(vr[it][e]), acc[2 * e + 1]); }
+  if (tid == 0)
+    is_last = __hip_atomic_fetch_add(counters + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
+  __syncthreads();
+  if (is_last) {
+    if (tid < D) {
+      const float r = kv_attn_combine_core(ws + (long)bh * nsplit * (D + 2), nsplit, tid, [](const float* p) { return ld_agent(p); });
+      out[(long)bh * D + tid] = f2bf(r);
     }
+    if (tid == 0) __hip_atomic_store(counters + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // reduce over the 4 key groups of a wave (lanes sub, sub+16, sub+32, sub+48), then over waves via LDS
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { acc[e] += __shfl_xor(acc[e], 16, 64); acc[e] += __shfl_xor(acc[e], 32, 64); }
-  lsum = wave_sum(lsum);
-  __syncthreads();
-  float* part = red + 8;     // [4][128]
-  if (kq == 0) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) part[wave * D + sub * 8 + e] = acc[e];
-  }
-  if (lane == 0) red[4 + wave] = lsum;
-  __syncthreads();
-  if (tid < D) out_ws[2 + tid] = part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid];
-  if (tid == 0) { out_ws[0] = mx; out_ws[1] = red[4] + red[5] + red[6] + red[7]; }
-}
-
-__global__ __launch_bounds__(128) void ld_kv_attn_combine_kernel(const float* ws, bf16_t* out, int nsplit) {
-  const int D = 128;
-  const int bh = blockIdx.x, d = threadIdx.x;
-  const float* w = ws + (long)bh * nsplit * (D + 2);
-  float mx = -3.0e38f;
-  for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, w[s * (D + 2)]);
-  float l = 0.f, o = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float f = __expf(w[s * (D + 2)] - mx);
-    l += f * w[s * (D + 2) + 1];
-    o += f * w[s * (D + 2) + 2 + d];
-  }
-  out[(long)bh * D + d] = f2bf(o / l);
 }
 
 // token embedding rows (fp32 table) -> bf16 features, same token for every batch row
@@ -1060,7 +949,7 @@ LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cach
   LD_REQUIRE(q || qkv_fused, "ld_llm_kv_attn: need q or qkv_fused");
   hipStream_t st = (hipStream_t)stream;
   if (m == 1 && nsplit > 1) {
-    LD_REQUIRE(workspace, "ld_llm_kv_attn: split path needs a workspace of B*H*nsplit*130 floats");
+    LD_REQUIRE(workspace, "ld_llm_kv_attn: split path needs a workspace of B*H*(nsplit*130 + 1) floats, the last B*H words zero");
     LD_REQUIRE(!qkv_fused || (cos_t && sin_t), "ld_llm_kv_attn: fused RoPE needs the cos/sin tables");
     LD_REQUIRE((Lmax + nsplit - 1) / nsplit <= 16 * KV_MAXIT, "ld_llm_kv_attn: Lmax=%ld needs nsplit >= %ld (<= 256 keys per split)",
                (long)Lmax, (long)((Lmax + 255) / 256));
@@ -1068,8 +957,8 @@ LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cach
     const size_t smem = (chunk + 8 + 4 * 128) * sizeof(float);
     hipLaunchKernelGGL(ld_kv_attn_split_kernel, dim3((unsigned)(B * H), (unsigned)nsplit), dim3(256), smem, st,
                        (const bf16_t*)q, (const bf16_t*)qkv_fused, cos_t, sin_t, (bf16_t*)k_cache, (bf16_t*)v_cache,
-                       (const int*)pos, workspace, (int)B, (int)H, (int)Lmax, (int)nsplit);
-    hipLaunchKernelGGL(ld_kv_attn_combine_kernel, dim3((unsigned)(B * H)), dim3(128), 0, st, workspace, (bf16_t*)out, (int)nsplit);
+                       (const int*)pos, workspace, (unsigned*)(workspace + B * H * nsplit * 130), (bf16_t*)out, (int)B, (int)H,
+                       (int)Lmax, (int)nsplit);
     return ld_check_launch("ld_llm_kv_attn(split)");
   }
   LD_REQUIRE(q && !qkv_fused, "ld_llm_kv_attn: the fused RoPE/append form exists only for the decode split path");

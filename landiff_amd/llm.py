@@ -124,9 +124,21 @@ class LLMRunner:
         # split-K decode attention: >= one workgroup per CU, and at most 256 keys per split (ld_llm_kv_attn)
         self.nsplit = max(1, 256 // (B * H), -(-self.Lmax // 256))
         self.top_k, self.top_p = None, None
-        self.attn_ws = e(B * H * self.nsplit * 130, dt=torch.float32)
+        # partial results [B*H][nsplit][130] + B*H arrival counters (zero between launches: the last split to arrive merges)
+        self.attn_ws = torch.zeros(B * H * (self.nsplit * 130 + 1), device=device, dtype=torch.float32)
         self._graph = None
         self._layer_table = None
+        # all blocks of a step in one persistent launch (ld_llm_fused.hip: same bits, the next operation's weights already in
+        # flight across each grid barrier).  Measured SLOWER than the per-operation chain so far (1.63 against 1.19 ms per
+        # step: six device-wide exchanges per block at 1.3-3 us each + 1-6 us of straggler spread), so it
+        # is opt-in: LD_LLM_FUSED=1 or sample(fused=True).  Its workgroups wait for each other, so it needs the GPU to itself:
+        # callers that decode UNDER another stream's kernels (generate_many, the streaming loop) pass fused=False.
+        self.fused = os.environ.get("LD_LLM_FUSED", "0") == "1"
+        self.fused_supported = (B == 2 and c.head_dim == 128 and c.hidden <= 2048 and c.mlp <= 12288 and self.nsplit >= 2
+                                and -(-self.Lmax // self.nsplit) <= 256)
+        self.fused_ctl = torch.zeros(ops.LLM_FUSED_CTL_WORDS, device=device, dtype=torch.int32)
+        self._use_fused = False
+        self._layer_table_dev = None
 
     # ---- conditioning ------------------------------------------------------------------------
     def _micro_cond(self, frames: float, motion_score: float):
@@ -194,6 +206,14 @@ class LLMRunner:
         c = self.cfg
         if self._layer_table is None:
             self._layer_table = ops.llm_layer_table(self.blocks, self.kc, self.vc)
+        if self._use_fused:
+            if self._layer_table_dev is None:
+                self._layer_table_dev = ops.llm_layer_table_device(self._layer_table, self.dev)
+            ops.llm_decode_forward_fused(self._layer_table_dev, len(self.blocks), None if self._x_from_tail else self.emb, self.token,
+                                         self.pos, self.x, self.qkv, self.att, self.gate, self.attn_ws, self.cos, self.sin,
+                                         self.ln_w, self.ln_b, self.lnf, self.head, self.logits, c.heads, self.Lmax, self.nsplit,
+                                         c.rms_eps, c.ln_eps, self.fused_ctl)
+            return
         ops.llm_decode_forward(self._layer_table, None if self._x_from_tail else self.emb, self.token, self.pos, self.x, self.qkv, self.att, self.gate,
                                self.attn_ws, self.cos, self.sin, self.ln_w, self.ln_b, self.lnf, self.head, self.logits,
                                c.heads, self.Lmax, self.nsplit, c.rms_eps, c.ln_eps)
@@ -234,7 +254,8 @@ class LLMRunner:
     def sample(self, text_emb: torch.Tensor, *, motion_score: float = 0.1, num_frames: int = 13, guidance_scale: float = 7.5,
                temperature: float = 1.0, seed: int | None = None, generator=None, use_graph: bool = False,
                teacher_fed=None, logits_log=None, top_k: int | None = None, top_p: float | None = None,
-               first_frame_tokens: torch.Tensor | None = None, on_segment=None, segment_tokens: int | None = None) -> torch.Tensor:
+               first_frame_tokens: torch.Tensor | None = None, on_segment=None, segment_tokens: int | None = None,
+               fused: bool | None = None) -> torch.Tensor:
         """Returns the clamped visual token ids, int64 [n_visual] on the device (lm_model.py:509-516).
         top_k / top_p filter the unrestricted positions inside the sampling kernel (lm_model.py:441-447).
         first_frame_tokens (int64 [iframe_len], e.g. from TokenizerEncoder.encode_to_index): use_gt_first_frame of the
@@ -245,6 +266,11 @@ class LLMRunner:
         order) -- lets a streaming caller start on segment s while later segments are still being decoded."""
         c, dev = self.cfg, self.dev
         self.top_k, self.top_p = top_k, top_p
+        # fused: the blocks of every decode step as one persistent launch (None: whenever the shapes allow it and LD_LLM_FUSED
+        # is not 0; False for a decode that runs concurrently with other streams' kernels)
+        self._use_fused = self.fused_supported and (self.fused if fused is None else fused)
+        if self._use_fused:
+            self.fused_ctl.zero_()
         guided = guidance_scale > 0 and guidance_scale != 1
         # unguided (ARSampleCfg's dataclass default cfg=0.0, lm_model.py:311-319): the conditional row is independent of the
         # second row, so the resident two-row buffers are kept and the sampling kernel reads row 0 only.
@@ -307,6 +333,9 @@ class LLMRunner:
             if logits_log is not None:
                 logits_log.append(self.cfg_logits.clone())
         self.host_enqueue_s = time.perf_counter() - t_enq      # host time to enqueue the loop (< wall time when the GPU is the bound)
+        if self._use_fused and int(self.fused_ctl[1].item()) != 0:
+            raise RuntimeError("ld_llm_decode_blocks_fused: a grid barrier timed out (the persistent decode kernel did not have the "
+                               "GPU to itself?); rerun with fused=False / LD_LLM_FUSED=0")
         assert int(self.out_count.item()) == n_visual, (int(self.out_count.item()), n_visual)
         out = self.out_tokens[:n_visual]
         if first_frame_tokens is not None:

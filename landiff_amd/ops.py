@@ -277,6 +277,30 @@ def llm_decode_forward(table, emb, token, pos, x, qkv, att, gate, attn_ws, cos_t
                                             float(ln_eps), _stream()), "ld_llm_decode_forward")
 
 
+LLM_FUSED_CTL_WORDS = 512          # LD_LLM_FUSED_CTL_WORDS
+
+
+def llm_layer_table_device(table, device):
+    """The ld_llm_layer array as a device tensor (the persistent decode kernel reads the table itself)."""
+    raw = bytes(memoryview(table).cast("B"))
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+def llm_decode_forward_fused(table_dev, n_layers, emb, token, pos, x, qkv, att, gate, attn_ws, cos_t, sin_t, lnf_w, lnf_b, lnf_out,
+                             head, logits, heads, Lmax, nsplit, rms_eps, ln_eps, ctl):
+    """llm_decode_forward with all blocks in one persistent launch (ld_llm_fused.hip); ctl: int32 [LLM_FUSED_CTL_WORDS], zeroed
+    before the first step of a decode.  Raises LandiffHipError(unsupported) outside the fused form's shapes."""
+    B, hidden = x.shape
+    for t in (x, qkv, att, gate, lnf_out, logits, head):
+        assert t.is_contiguous()
+    assert ctl.dtype == torch.int32 and ctl.numel() >= LLM_FUSED_CTL_WORDS
+    check(_lib.load().ld_llm_decode_forward_fused(_ptr(table_dev), n_layers, _ptr(emb), _ptr(token), _ptr(pos), _ptr(x), _ptr(qkv),
+                                                  _ptr(att), _ptr(gate), _ptr(attn_ws), _ptr(cos_t), _ptr(sin_t), _ptr(lnf_w),
+                                                  _ptr(lnf_b), _ptr(lnf_out), _ptr(head), _ptr(logits), B, hidden, heads,
+                                                  gate.shape[1], logits.shape[1], Lmax, nsplit, float(rms_eps), float(ln_eps),
+                                                  _ptr(ctl), _stream()), "ld_llm_decode_forward_fused")
+
+
 def llm_logits_to_probs(logits, probs, cfg_logits, guided, scale, temperature, pos=None, allowed=None,
                         top_k=None, top_p=None):
     V = probs.shape[-1]
