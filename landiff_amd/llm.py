@@ -200,7 +200,7 @@ class LLMRunner:
 
     def _decode_forward(self):
         """One token: embedding of *token at position *pos -> logits [2, V].  All sizes are static and every per-step scalar
-        lives on the device; the ~150 launches are queued by ONE native call (ld_llm_decode_forward) -- issued one by one
+        lives on the device; the ~125 launches are queued by ONE native call (ld_llm_decode_forward) -- issued one by one
         from Python the step was bound by the interpreter (1.3 ms of host time per step), and replaying it as a HIP graph
         costs 1.2 ms of host time per launch of the 164-node graph."""
         c = self.cfg

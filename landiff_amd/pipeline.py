@@ -350,7 +350,7 @@ def gather_prompt_frames(local_frames: list, n_prompts: int, rank: int, world: i
 
 def rank_core_slice(local_rank: int, local_world: int, cores: list | None = None) -> list:
     """The host cores of one rank: the cores this process may run on (its cpuset), cut into `local_world` contiguous, disjoint
-    slices.  One process per GPU each runs a latency-sensitive enqueue loop (the AR decode queues ~150 launches per 1.3 ms
+    slices.  One process per GPU each runs a latency-sensitive enqueue loop (the AR decode queues ~125 launches per 1.2 ms
     step from one thread, 0.54 ms of host time per step): eight of them left to the scheduler migrate across cores and share
     caches; a fixed slice per rank keeps every rank's enqueue thread, its helper thread (generate_many / generate_stream) and
     its RCCL proxy thread on cores of their own."""

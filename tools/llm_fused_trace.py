@@ -41,3 +41,13 @@ for k in range(6):
     arr, ex = tb[:, 2 * k] - t0, tb[:, 2 * k + 1] - t0
     print(f"  barrier {k + 1}: arrivals {arr.min():7.2f} .. {arr.max():7.2f} (median {arr.median():7.2f}), exits {ex.min():7.2f} .. {ex.max():7.2f};"
           f"  last arrival -> median exit {ex.median() - arr.max():5.2f} us")
+
+# who are the stragglers?  phase time of every workgroup = arrival at barrier k+1 - exit of barrier k, by XCD (workgroup id & 7)
+names = ["attention", "combine", "wo", "w13", "w2"]
+for k, nm in enumerate(names):
+    dur = tb[:, 2 * (k + 1)] - tb[:, 2 * k + 1]
+    by_xcd = [dur[x::8] for x in range(8)]
+    print(f"  {nm:9s} per-XCD mean: " + " ".join(f"{d.mean():6.2f}" for d in by_xcd) + f"   | all: min {dur.min():.2f} median {dur.median():.2f} max {dur.max():.2f}")
+    if nm in ("w13", "w2"):
+        order = torch.argsort(dur, descending=True)[:12]
+        print("            slowest workgroups: " + " ".join(f"{int(i)}({dur[i]:.1f})" for i in order))
