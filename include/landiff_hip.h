@@ -235,6 +235,26 @@ int ld_llm_decode_forward_fused(const ld_llm_layer* layers_dev, int64_t n_layers
                                 int64_t vocab, int64_t Lmax, int64_t nsplit, float rms_eps, float ln_eps, uint32_t* ctl,
                                 void* stream);
 
+/* The blocks of the same step as DEPENDENT LAUNCHES ON TWO STREAMS: operation k (5 per block: qkv, attention, wo, w1.w3, w2) goes
+ * to stream k & 1 with no stream dependency on operation k - 1; its workgroups request their first weight rows (the attention: its
+ * K / V rows), then wait until every workgroup of operation k - 1 has arrived on that operation's counters, and arrive on their own
+ * when their outputs are written (sc1) and drained -- a launch is dispatched and streaming weights while its predecessor runs.
+ * Identical bits.  layers: HOST table (as ld_llm_decode_forward).  pos_value: the position *pos holds (the host knows it: one
+ * more per step) -- the launches do not read *pos, so they do not depend on the previous step's sampling launch.  ctl:
+ * LD_LLM_CHAIN_CTL_WORDS words of device memory, zeroed before the first step of a decode (word 0: error flag, set when a wait
+ * timed out after ~1 s -- later waits then fall through); epoch: steps done since the zeroing.  Caller's duties: stream1 must
+ * be ordered after whatever wrote the KV cache / x before the first step (e.g. the prefill), and whatever reads x after the call
+ * must be ordered after BOTH streams.  Every launch fits twice on the chip (<= 128 registers, <= 512 workgroups; the attention
+ * half the chip), so the waiting launch can never keep its predecessor from becoming resident -- provided nothing else occupies
+ * the GPU for long.  LD_ERR_UNSUPPORTED outside B == 2, head_dim 128, hidden <= 4096, mlp <= 12288, <= 256 keys per split,
+ * 5 * n_layers <= LD_LLM_CHAIN_MAX_OPS. */
+#define LD_LLM_CHAIN_MAX_OPS 256
+#define LD_LLM_CHAIN_CTL_WORDS (64 + LD_LLM_CHAIN_MAX_OPS * 8 * 16)
+int ld_llm_decode_blocks_chained(const ld_llm_layer* layers, int64_t n_layers, int32_t pos_value, void* x, void* qkv, void* att,
+                                 void* gate, float* attn_ws, const float* cos_t, const float* sin_t, int64_t B, int64_t hidden,
+                                 int64_t heads, int64_t mlp, int64_t Lmax, int64_t nsplit, float rms_eps, uint32_t* ctl,
+                                 uint32_t epoch, void* stream0, void* stream1);
+
 /* nn.Embedding lookup of *token (fp32 table [V][D]) -> bf16 features [B][D] (landiff/llm/modules/tokenizer.py:10-55). */
 int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B, int64_t D, void* stream);
 

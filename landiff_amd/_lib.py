@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_void_p, c_float, c_double
+from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_uint32, c_void_p, c_float, c_double
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LANDIFF_HIP_LIB: another build of the same library (tools/: A/B of compile-time variants); the product never sets it
@@ -75,6 +75,7 @@ SIGNATURES: dict[str, list] = {
     "ld_vq_nearest": [P, I64, P, P, I64, I64, I64, P],
     "ld_llm_decode_forward": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
                               c_float, c_float, P],
+    "ld_llm_decode_blocks_chained": [P, I64, I32, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_float, P, c_uint32, P, P],
     "ld_llm_decode_blocks_fused": [P, I64, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_float, P, P],
     "ld_llm_decode_forward_fused": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
                                     c_float, c_float, P, P],

@@ -36,6 +36,7 @@ struct GemvParams {
   int in_act, act;
   const float* norm_w;  // optional fused RMSNorm of x (bf16 x only): xn = bf16(x * rsqrt(mean(x^2)+eps) * norm_w)
   float norm_eps;
+  ChainSync cs;         // dependent-launch form (ld_gemv_reg_kernel<..., CHAIN = true> only)
 };
 
 // Weight-streaming GEMV.  One workgroup = 4 waves x R rows.  The activation rows (B x K, optionally RMS-normalised,
@@ -272,11 +273,16 @@ __global__ __launch_bounds__(256) void ld_gemv_kernel(GemvParams p) {
 // sums are reduced across the wave with a transposing butterfly (V + 6 - log2 V shuffles for V values instead of
 // 6 V) and across the 4 waves through LDS.
 // ---------------------------------------------------------------------------------------------
-template <int B, int R, int J, bool GATED, bool NORM>
-__global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbatch) {
+// CHAIN: the dependent-launch form (ld_llm_dev.h: ChainSync) -- the first batch of weight rows is requested BEFORE the wait for
+// the previous operation, x / residual / outputs go through sc1 accesses, the workgroup arrives on its counter at the end;
+// at most 128 registers so that two such launches are always resident side by side (grids capped at 512 workgroups).
+template <int B, int R, int J, bool GATED, bool NORM, bool CHAIN = false>
+__global__ __launch_bounds__(256, CHAIN ? 4 : 1) void ld_gemv_reg_kernel(GemvParams p, int nbatch) {
   constexpr int NV = R * B * (GATED ? 2 : 1), V = ceil_pow2(NV), LOGV = ilog2(V);
+  constexpr int XAUX = CHAIN ? 16 : 0;                 // sc1 on the activation loads
   __shared__ float red[2][4][V];
   __shared__ float ssq[4][B];
+  __shared__ int chain_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunk = p.K >> 3;
   const int er = tid / B, eb = tid - er * B;          // this thread's epilogue output within a batch: (row er, batch row eb)
@@ -305,7 +311,10 @@ __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbat
     const int en = n0 + er;
     if (tid < R * B && en < p.N) {
       if (p.bias) e_bias_n = p.bias[en];
-      if (p.resid) e_res_n = p.out_f32 ? ((const uint32_t*)p.resid)[eb * p.ldr + en] : (uint32_t)((const bf16_t*)p.resid)[eb * p.ldr + en];
+      if (p.resid) {
+        if (CHAIN) e_res_n = __hip_atomic_load((const bf16_t*)p.resid + eb * p.ldr + en, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else e_res_n = p.out_f32 ? ((const uint32_t*)p.resid)[eb * p.ldr + en] : (uint32_t)((const bf16_t*)p.resid)[eb * p.ldr + en];
+      }
     }
   };
 
@@ -315,11 +324,16 @@ __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbat
   // bounds-checked buffer loads (chunks past K read as zero): no branch and no zero-initialised destination -- with predicated
   // global loads the register allocator placed a v_mov behind every x load and the wave waited for each load in turn BEFORE the
   // first weight row had been requested (one L2 round trip per launch, six in the K = 11008 form)
+  int batch = blockIdx.x;
+  if (CHAIN) {                                         // weights do not depend on the previous operation: request, then wait for it
+    request(batch);
+    chain_wait(p.cs, tid, &chain_flag);
+  }
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.x + b * p.ldx), 0, p.K * 2, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < J; ++j) xq[b][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (j * 256 + tid) * 16, 0, 0);
+    for (int j = 0; j < J; ++j) xq[b][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (j * 256 + tid) * 16, 0, XAUX);
   }
   if (NORM) {
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.norm_w, 0, p.K * 4, 0x00020000);
@@ -330,8 +344,7 @@ __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbat
       g0[j] = __builtin_bit_cast(f32x4_t, a); g1[j] = __builtin_bit_cast(f32x4_t, b);
     }
   }
-  int batch = blockIdx.x;
-  request(batch);
+  if (!CHAIN) request(batch);
 
   // ---- x: optional fused RMSNorm (transformer_blocks.py:22-40), back to packed bf16 ----
   if (NORM) {
@@ -396,10 +409,12 @@ __global__ __launch_bounds__(256) void ld_gemv_reg_kernel(GemvParams p, int nbat
       if (p.act) a = rbf(apply_act(p.act, a));
       if (GATED) a = rbf(a * rbf(rd[0][R * B + tid] + rd[1][R * B + tid] + rd[2][R * B + tid] + rd[3][R * B + tid]));
       if (p.resid) a = p.out_f32 ? e_res + a : rbf(e_res + a);
-      if (p.out_f32) ((float*)p.out)[eb * p.ldo + en] = a;
+      if (CHAIN) __hip_atomic_store((bf16_t*)p.out + eb * p.ldo + en, f2bf(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (p.out_f32) ((float*)p.out)[eb * p.ldo + en] = a;
       else ((bf16_t*)p.out)[eb * p.ldo + en] = f2bf(a);
     }
   }
+  if (CHAIN) chain_arrive(p.cs, tid, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -606,16 +621,20 @@ __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store
 // the stores and arrives on the (batch row, head)'s counter; the LAST one to arrive reads all partial results (sc1 loads),
 // writes the attention output and leaves the counter at zero for the next launch.  Nobody waits for anybody (no co-residency
 // requirement); one launch and one ~5 us dependent kernel per block less than split + combine.
-__global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, const bf16_t* qkv, const float* cos_t,
+// CHAIN: dependent-launch form (ChainSync): the K / V rows (earlier steps' data) are requested before the wait for the qkv
+// operation, the new token's q / k / v come through sc1 loads, the merged output is written sc1, every workgroup arrives at the
+// end; pos_value >= 0 replaces the device-side position (no dependence on the previous step's sampling launch).
+template <bool CHAIN>
+__global__ __launch_bounds__(256, CHAIN ? 2 : 1) void ld_kv_attn_split_kernel(const bf16_t* q, const bf16_t* qkv, const float* cos_t,
                                                                const float* sin_t, bf16_t* kc, bf16_t* vc,
-                                                               const int* pos_ptr, float* ws, unsigned* counters, bf16_t* out,
-                                                               int B, int H, int Lmax, int nsplit) {
+                                                               const int* pos_ptr, int pos_value, float* ws, unsigned* counters,
+                                                               bf16_t* out, int B, int H, int Lmax, int nsplit, ChainSync cs) {
   extern __shared__ float sc[];       // [chunk] (unused since the scores live in registers) + reductions
   __shared__ int is_last;
   const int D = 128;
   const int bh = blockIdx.x, sp = blockIdx.y;
   const int b = bh / H, h = bh - b * H;
-  const int L = *pos_ptr + 1;
+  const int L = (pos_value >= 0 ? pos_value : *pos_ptr) + 1;
   const int chunk = (L + nsplit - 1) / nsplit;
   const int k_begin = sp * chunk, k_end = min(L, k_begin + chunk);
   const int n = max(0, k_end - k_begin);
@@ -623,6 +642,11 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
   const int sub = lane & 15, kq = lane >> 4;
   float* out_ws = ws + ((long)bh * nsplit + sp) * (D + 2);
   float* red = sc + ((Lmax + nsplit - 1) / nsplit + 16);
+  KvRows rows;
+  if (CHAIN) {
+    if (n > 0) kv_rows_request(rows, kc, vc, (long)b * Lmax + k_begin, H, h, n, wave, kq, sub);
+    chain_wait(cs, tid, &is_last);
+  }
   if (n == 0) {
     if (tid < D) st_agent(out_ws + 2 + tid, 0.f);
     if (tid == 0) { st_agent(out_ws, -3.0e38f); st_agent(out_ws + 1, 0.f); }
@@ -632,21 +656,27 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
     // arithmetic runs underneath it.  The key being appended this step is taken from qkv directly (its cache slot is
     // written for later steps but not read back here), so the prologue needs no barrier.
     u32x4_t a_q = (u32x4_t){0u, 0u, 0u, 0u}, a_k = a_q, a_v = a_q;
-    float cs[4] = {0.f, 0.f, 0.f, 0.f}, sn[4] = {0.f, 0.f, 0.f, 0.f};
+    float cs_[4] = {0.f, 0.f, 0.f, 0.f}, sn[4] = {0.f, 0.f, 0.f, 0.f};
     const int pos = L - 1;
     if (qkv) {
       const bf16_t* src = qkv + ((long)b * 3 * H + h) * D;      // [B][3][H][128]: q at +0, k at +H*D, v at +2*H*D
-      a_q = *(const u32x4_t*)(src + sub * 8);
-      a_k = *(const u32x4_t*)(src + (long)H * D + sub * 8);
-      a_v = *(const u32x4_t*)(src + 2L * H * D + sub * 8);
+      if (CHAIN) {
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (2 * H + 1) * D * 2, 0x00020000);
+        a_q = __builtin_amdgcn_raw_buffer_load_b128(rq, sub * 16, 0, 16);
+        a_k = __builtin_amdgcn_raw_buffer_load_b128(rq, (H * D + sub * 8) * 2, 0, 16);
+        a_v = __builtin_amdgcn_raw_buffer_load_b128(rq, (2 * H * D + sub * 8) * 2, 0, 16);
+      } else {
+        a_q = *(const u32x4_t*)(src + sub * 8);
+        a_k = *(const u32x4_t*)(src + (long)H * D + sub * 8);
+        a_v = *(const u32x4_t*)(src + 2L * H * D + sub * 8);
+      }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { cs[e] = cos_t[pos * 64 + sub * 4 + e]; sn[e] = sin_t[pos * 64 + sub * 4 + e]; }
+      for (int e = 0; e < 4; ++e) { cs_[e] = cos_t[pos * 64 + sub * 4 + e]; sn[e] = sin_t[pos * 64 + sub * 4 + e]; }
     } else {
       a_q = *(const u32x4_t*)(q + ((long)b * H + h) * D + sub * 8);
     }
-    KvRows rows;
-    kv_rows_request(rows, kc, vc, (long)b * Lmax + k_begin, H, h, n, wave, kq, sub);
-    kv_attn_split_core(rows, a_q, a_k, a_v, cs, sn, qkv != nullptr, kc, vc, (long)b * Lmax + pos, H, h, pos - k_begin, n, true,
+    if (!CHAIN) kv_rows_request(rows, kc, vc, (long)b * Lmax + k_begin, H, h, n, wave, kq, sub);
+    kv_attn_split_core(rows, a_q, a_k, a_v, cs_, sn, qkv != nullptr, kc, vc, (long)b * Lmax + pos, H, h, pos - k_begin, n, true,
                        out_ws, red, red + 8, tid, lane, wave, [](float* p, float v) { st_agent(p, v); });
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's part of the partial result is at the coherence point
@@ -657,10 +687,12 @@ __global__ __launch_bounds__(256) void ld_kv_attn_split_kernel(const bf16_t* q, 
   if (is_last) {
     if (tid < D) {
       const float r = kv_attn_combine_core(ws + (long)bh * nsplit * (D + 2), nsplit, tid, [](const float* p) { return ld_agent(p); });
-      out[(long)bh * D + tid] = f2bf(r);
+      if (CHAIN) __hip_atomic_store(out + (long)bh * D + tid, f2bf(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else out[(long)bh * D + tid] = f2bf(r);
     }
     if (tid == 0) __hip_atomic_store(counters + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (CHAIN) chain_arrive(cs, tid, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // token embedding rows (fp32 table) -> bf16 features, same token for every batch row
@@ -955,10 +987,10 @@ LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cach
                (long)Lmax, (long)((Lmax + 255) / 256));
     const size_t chunk = (size_t)((Lmax + nsplit - 1) / nsplit + 16);
     const size_t smem = (chunk + 8 + 4 * 128) * sizeof(float);
-    hipLaunchKernelGGL(ld_kv_attn_split_kernel, dim3((unsigned)(B * H), (unsigned)nsplit), dim3(256), smem, st,
+    hipLaunchKernelGGL(ld_kv_attn_split_kernel<false>, dim3((unsigned)(B * H), (unsigned)nsplit), dim3(256), smem, st,
                        (const bf16_t*)q, (const bf16_t*)qkv_fused, cos_t, sin_t, (bf16_t*)k_cache, (bf16_t*)v_cache,
-                       (const int*)pos, workspace, (unsigned*)(workspace + B * H * nsplit * 130), (bf16_t*)out, (int)B, (int)H,
-                       (int)Lmax, (int)nsplit);
+                       (const int*)pos, -1, workspace, (unsigned*)(workspace + B * H * nsplit * 130), (bf16_t*)out, (int)B, (int)H,
+                       (int)Lmax, (int)nsplit, ChainSync{});
     return ld_check_launch("ld_llm_kv_attn(split)");
   }
   LD_REQUIRE(q && !qkv_fused, "ld_llm_kv_attn: the fused RoPE/append form exists only for the decode split path");
@@ -1011,6 +1043,82 @@ LD_API int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, c
   if (rc) return rc;
   return ld_gemv(lnf_out, hidden, 1, head_w, nullptr, 1, nullptr, nullptr, 0, logits, vocab, 1, B, vocab, hidden, 0, 0,
                  nullptr, 0.f, stream);
+}
+
+namespace {
+// the register GEMV in its dependent-launch form (B = 2): variant choice of launch_gemv_b, <= 128 registers, <= 512 workgroups
+template <int R, int J, bool GATED, bool NORM>
+int launch_gemv_chain(const GemvParams& p, hipStream_t st, int* grid_out) {
+  const int cap = 512;
+  const int nbatch = (p.N + R - 1) / R;
+  const int trips = (nbatch + cap - 1) / cap;
+  const int grid = (nbatch + trips - 1) / trips;
+  *grid_out = grid;
+  hipLaunchKernelGGL((ld_gemv_reg_kernel<2, R, J, GATED, NORM, true>), dim3((unsigned)grid), dim3(256), 0, st, p, nbatch);
+  return ld_check_launch("ld_gemv(chained)");
+}
+int gemv_chain(const GemvParams& p, hipStream_t st, int* grid_out) {
+  const int nchunk = p.K >> 3;
+  const bool gated = p.W2 != nullptr, norm = p.norm_w != nullptr;
+  if (nchunk <= 256) {
+    if (gated) return norm ? launch_gemv_chain<4, 1, true, true>(p, st, grid_out) : ld_set_error(LD_ERR_UNSUPPORTED, "chained gemv: gated without norm");
+    return norm ? launch_gemv_chain<4, 1, false, true>(p, st, grid_out) : launch_gemv_chain<4, 1, false, false>(p, st, grid_out);
+  }
+  if (nchunk <= 512) {
+    if (gated) return norm ? launch_gemv_chain<2, 2, true, true>(p, st, grid_out) : ld_set_error(LD_ERR_UNSUPPORTED, "chained gemv: gated without norm");
+    return norm ? launch_gemv_chain<4, 2, false, true>(p, st, grid_out) : launch_gemv_chain<4, 2, false, false>(p, st, grid_out);
+  }
+  if (nchunk <= 1536 && !gated && !norm) return launch_gemv_chain<1, 6, false, false>(p, st, grid_out);
+  return ld_set_error(LD_ERR_UNSUPPORTED, "chained gemv: K = %d outside the register forms", p.K);
+}
+}  // namespace
+
+LD_API int ld_llm_decode_blocks_chained(const ld_llm_layer* layers, int64_t n_layers, int32_t pos_value, void* x, void* qkv, void* att,
+                                        void* gate, float* attn_ws, const float* cos_t, const float* sin_t, int64_t B, int64_t hidden,
+                                        int64_t heads, int64_t mlp, int64_t Lmax, int64_t nsplit, float rms_eps, uint32_t* ctl,
+                                        uint32_t epoch, void* stream0, void* stream1) {
+  LD_REQUIRE(layers && n_layers > 0 && x && qkv && att && gate && attn_ws && cos_t && sin_t && ctl, "ld_llm_decode_blocks_chained: null pointer");
+  LD_REQUIRE(pos_value >= 0 && pos_value < Lmax, "ld_llm_decode_blocks_chained: position %d outside [0, Lmax)", (int)pos_value);
+  LD_REQUIRE(stream0 != stream1, "ld_llm_decode_blocks_chained: needs two different streams");
+  if (B != 2 || hidden != heads * 128 || hidden % 8 || hidden > 4096 || mlp % 8 || mlp > 12288 || nsplit < 2 ||
+      (Lmax + nsplit - 1) / nsplit > 16 * KV_MAXIT || 5 * n_layers > LD_LLM_CHAIN_MAX_OPS)
+    return ld_set_error(LD_ERR_UNSUPPORTED, "ld_llm_decode_blocks_chained: B=%ld hidden=%ld heads=%ld mlp=%ld Lmax=%ld nsplit=%ld layers=%ld "
+                        "outside the chained form", (long)B, (long)hidden, (long)heads, (long)mlp, (long)Lmax, (long)nsplit, (long)n_layers);
+  hipStream_t st[2] = {(hipStream_t)stream0, (hipStream_t)stream1};
+  int slot = 0, prev_grid = 0, rc = 0;
+  auto sync = [&]() { return ChainSync{(unsigned*)ctl, slot, prev_grid, epoch + 1u}; };
+  auto gemv = [&](const void* xin, int64_t ldx, const void* W, const void* W2, const void* resid, void* out, int64_t ldo, int64_t N, int64_t K,
+                  int act, const float* norm_w) {
+    GemvParams p{};
+    p.x = xin; p.W = W; p.W2 = W2; p.resid = resid; p.out = out; p.B = 2; p.N = (int)N; p.K = (int)K; p.ldx = ldx; p.ldo = ldo; p.ldr = ldo;
+    p.act = act; p.norm_w = norm_w; p.norm_eps = rms_eps; p.cs = sync();
+    int grid = 0;
+    const int r = gemv_chain(p, st[slot & 1], &grid);
+    prev_grid = grid; ++slot;
+    return r;
+  };
+  const size_t chunk = (size_t)((Lmax + nsplit - 1) / nsplit + 16);
+  const size_t smem = (chunk + 8 + 4 * 128) * sizeof(float);
+  for (int64_t i = 0; i < n_layers && rc == 0; ++i) {
+    const ld_llm_layer& w = layers[i];
+    LD_REQUIRE(w.wqkv && w.wo && w.w1 && w.w3 && w.w2 && w.n0 && w.n1 && w.k_cache && w.v_cache,
+               "ld_llm_decode_blocks_chained: layer %ld has a null pointer", (long)i);
+    rc = gemv(x, hidden, w.wqkv, nullptr, nullptr, qkv, 3 * hidden, 3 * hidden, hidden, 0, w.n0);
+    if (rc) break;
+    hipLaunchKernelGGL(ld_kv_attn_split_kernel<true>, dim3((unsigned)(B * heads), (unsigned)nsplit), dim3(256), smem, st[slot & 1],
+                       (const bf16_t*)nullptr, (const bf16_t*)qkv, cos_t, sin_t, (bf16_t*)w.k_cache, (bf16_t*)w.v_cache, (const int*)nullptr,
+                       (int)pos_value, attn_ws, (unsigned*)(attn_ws + B * heads * nsplit * 130), (bf16_t*)att, (int)B, (int)heads,
+                       (int)Lmax, (int)nsplit, sync());
+    rc = ld_check_launch("ld_llm_kv_attn(chained)");
+    if (rc) break;
+    prev_grid = (int)(B * heads * nsplit); ++slot;
+    rc = gemv(att, hidden, w.wo, nullptr, x, x, hidden, hidden, hidden, 0, nullptr);
+    if (rc) break;
+    rc = gemv(x, hidden, w.w1, w.w3, nullptr, gate, mlp, mlp, hidden, LD_ACT_GELU_TANH, w.n1);
+    if (rc) break;
+    rc = gemv(gate, mlp, w.w2, nullptr, x, x, hidden, hidden, mlp, 0, nullptr);
+  }
+  return rc;
 }
 
 LD_API int ld_llm_logits_to_probs(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided,

@@ -188,3 +188,50 @@ __device__ __forceinline__ float kv_attn_combine_core(const float* w, int nsplit
   }
   return o / l;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Dependent launches on two streams (ld_llm_decode_blocks_chained): operation k of a decode step is launched on stream k & 1
+// with NO stream dependency on operation k - 1; instead its workgroups request their first weight rows, then wait until every
+// workgroup of operation k - 1 has arrived on that operation's counters (its outputs written sc1 and drained), and arrive on
+// their own counters when done.  A launch is therefore dispatched, resident and streaming weights while its predecessor is
+// still running.  ctl: word 0 = error flag; slot s, counter c at word 64 + (s * 8 + c) * 16; workgroup w arrives on counter
+// w & 7; counters are never reset inside a decode: the target of epoch e (1-based step count) is e * (workgroups on it).
+// ---------------------------------------------------------------------------------------------
+struct ChainSync {
+  unsigned* ctl;         // null: plain launch
+  int slot;              // this operation's counter slot
+  int prev_grid;         // workgroups of the operation waited for (0: none)
+  unsigned epoch1;       // 1-based step count since the control block was zeroed
+};
+constexpr int CHAIN_CTR0 = 64, CHAIN_CSTRIDE = 16, CHAIN_NCTR = 8;
+constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 20;
+
+// every thread of the workgroup calls it; one workgroup barrier inside
+__device__ __forceinline__ void chain_wait(const ChainSync& cs, int tid, int* flag) {
+  if (cs.prev_grid > 0 && tid < 64) {
+    const unsigned* ctr = cs.ctl + CHAIN_CTR0 + (cs.slot - 1) * CHAIN_NCTR * CHAIN_CSTRIDE;
+    const unsigned mine = tid < CHAIN_NCTR ? cs.epoch1 * (unsigned)((cs.prev_grid - tid + CHAIN_NCTR - 1) / CHAIN_NCTR) : 0u;
+    unsigned spins = 0;
+    while (true) {
+      const unsigned v = tid < CHAIN_NCTR ? __hip_atomic_load(ctr + tid * CHAIN_CSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      if (__builtin_amdgcn_ballot_w64(v < mine) == 0) break;
+      if ((spins & 63) == 63 && __hip_atomic_load(cs.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // somebody gave up: run through
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > CHAIN_SPIN_LIMIT) {
+        if (tid == 0) __hip_atomic_store(cs.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  (void)flag;
+  __syncthreads();
+}
+
+// after the operation's last (sc1) store of this thread; wg = linear workgroup id
+__device__ __forceinline__ void chain_arrive(const ChainSync& cs, int tid, int wg) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0)
+    __hip_atomic_fetch_add(cs.ctl + CHAIN_CTR0 + (cs.slot * CHAIN_NCTR + (wg & (CHAIN_NCTR - 1))) * CHAIN_CSTRIDE, 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}

@@ -128,17 +128,27 @@ class LLMRunner:
         self.attn_ws = torch.zeros(B * H * (self.nsplit * 130 + 1), device=device, dtype=torch.float32)
         self._graph = None
         self._layer_table = None
-        # all blocks of a step in one persistent launch (ld_llm_fused.hip: same bits, the next operation's weights already in
-        # flight across each grid barrier).  Measured SLOWER than the per-operation chain so far (1.63 against 1.19 ms per
-        # step: six device-wide exchanges per block at 1.3-3 us each + 1-6 us of straggler spread), so it
-        # is opt-in: LD_LLM_FUSED=1 or sample(fused=True).  Its workgroups wait for each other, so it needs the GPU to itself:
-        # callers that decode UNDER another stream's kernels (generate_many, the streaming loop) pass fused=False.
-        self.fused = os.environ.get("LD_LLM_FUSED", "0") == "1"
+        # Three forms of a decode step's blocks, identical bits (tests/test_gpu_stages.py, tests/test_gpu_fullsize.py):
+        #   "chain"    one launch per operation on the current stream (5 per block);
+        #   "chained"  the same launches alternating between two streams with device-side dependencies (every launch requests
+        #              its first weight rows while its predecessor is still running; ld_llm_decode_blocks_chained);
+        #   "fused"    all blocks in one persistent launch with grid barriers (ld_llm_fused.hip; measured slower, opt-in).
+        # "chained" and "fused" need the GPU to themselves (their workgroups wait for other workgroups): callers that decode
+        # UNDER another stream's kernels (generate_many, the streaming loop) pass mode="chain".  LD_LLM_DECODE overrides the default.
+        self.decode_mode = os.environ.get("LD_LLM_DECODE", "chain")
+        assert self.decode_mode in ("chain", "chained", "fused"), self.decode_mode
         self.fused_supported = (B == 2 and c.head_dim == 128 and c.hidden <= 2048 and c.mlp <= 12288 and self.nsplit >= 2
                                 and -(-self.Lmax // self.nsplit) <= 256)
+        self.chained_supported = (B == 2 and c.head_dim == 128 and c.hidden <= 4096 and c.mlp <= 12288 and self.nsplit >= 2
+                                  and -(-self.Lmax // self.nsplit) <= 256 and 5 * c.num_layers <= 256)
         self.fused_ctl = torch.zeros(ops.LLM_FUSED_CTL_WORDS, device=device, dtype=torch.int32)
-        self._use_fused = False
+        self.chain_ctl = torch.zeros(ops.LLM_CHAIN_CTL_WORDS, device=device, dtype=torch.int32)
+        self._mode = "chain"               # the form the running decode uses
         self._layer_table_dev = None
+        self._side = None                  # second stream + event of the chained form
+        self._chain_ev = None
+        self._chain_epoch = 0
+        self._pos_host = 0                 # host mirror of *pos (one more per step)
 
     # ---- conditioning ------------------------------------------------------------------------
     def _micro_cond(self, frames: float, motion_score: float):
@@ -206,7 +216,20 @@ class LLMRunner:
         c = self.cfg
         if self._layer_table is None:
             self._layer_table = ops.llm_layer_table(self.blocks, self.kc, self.vc)
-        if self._use_fused:
+        if self._mode == "chained":
+            s0 = torch.cuda.current_stream(self.dev)
+            if not self._x_from_tail:
+                ops.llm_embed(self.emb, self.token, self.x)
+            ops.llm_decode_blocks_chained(self._layer_table, self._pos_host, self.x, self.qkv, self.att, self.gate, self.attn_ws,
+                                          self.cos, self.sin, c.heads, self.Lmax, self.nsplit, c.rms_eps, self.chain_ctl,
+                                          self._chain_epoch, s0, self._side)
+            self._chain_epoch += 1
+            self._chain_ev.record(self._side)              # the step's last operation may sit on either stream: the tail follows both
+            s0.wait_event(self._chain_ev)
+            ops.layernorm_bf16_to_f32(self.x, self.ln_w, self.ln_b, self.lnf, c.ln_eps)
+            ops.gemv(self.lnf, self.head, self.logits)
+            return
+        if self._mode == "fused":
             if self._layer_table_dev is None:
                 self._layer_table_dev = ops.llm_layer_table_device(self._layer_table, self.dev)
             ops.llm_decode_forward_fused(self._layer_table_dev, len(self.blocks), None if self._x_from_tail else self.emb, self.token,
@@ -255,7 +278,7 @@ class LLMRunner:
                temperature: float = 1.0, seed: int | None = None, generator=None, use_graph: bool = False,
                teacher_fed=None, logits_log=None, top_k: int | None = None, top_p: float | None = None,
                first_frame_tokens: torch.Tensor | None = None, on_segment=None, segment_tokens: int | None = None,
-               fused: bool | None = None) -> torch.Tensor:
+               mode: str | None = None) -> torch.Tensor:
         """Returns the clamped visual token ids, int64 [n_visual] on the device (lm_model.py:509-516).
         top_k / top_p filter the unrestricted positions inside the sampling kernel (lm_model.py:441-447).
         first_frame_tokens (int64 [iframe_len], e.g. from TokenizerEncoder.encode_to_index): use_gt_first_frame of the
@@ -266,11 +289,13 @@ class LLMRunner:
         order) -- lets a streaming caller start on segment s while later segments are still being decoded."""
         c, dev = self.cfg, self.dev
         self.top_k, self.top_p = top_k, top_p
-        # fused: the blocks of every decode step as one persistent launch (None: whenever the shapes allow it and LD_LLM_FUSED
-        # is not 0; False for a decode that runs concurrently with other streams' kernels)
-        self._use_fused = self.fused_supported and (self.fused if fused is None else fused)
-        if self._use_fused:
-            self.fused_ctl.zero_()
+        # mode: the form of a decode step's blocks ("chain" / "chained" / "fused", see __init__; None: the runner's default);
+        # an unsupported shape falls back to "chain"
+        mode = self.decode_mode if mode is None else mode
+        assert mode in ("chain", "chained", "fused"), mode
+        if (mode == "fused" and not self.fused_supported) or (mode == "chained" and (not self.chained_supported or use_graph)):
+            mode = "chain"
+        self._mode = mode
         guided = guidance_scale > 0 and guidance_scale != 1
         # unguided (ARSampleCfg's dataclass default cfg=0.0, lm_model.py:311-319): the conditional row is independent of the
         # second row, so the resident two-row buffers are kept and the sampling kernel reads row 0 only.
@@ -312,6 +337,16 @@ class LLMRunner:
         self._prefill(feats)
         self.pos.fill_(S_last)
         self._sample_and_advance(guided, guidance_scale, temperature, generator)
+        self._pos_host = S_last + 1
+        if self._mode == "fused":
+            self.fused_ctl.zero_()
+        elif self._mode == "chained":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+                self._chain_ev = torch.cuda.Event()
+            self.chain_ctl.zero_()
+            self._chain_epoch = 0
+            self._side.wait_stream(torch.cuda.current_stream(dev))      # the prefill's KV cache and the zeroed counters
         note_position(S_last + 1)
         if logits_log is not None:
             logits_log.append(self.cfg_logits.clone())
@@ -329,13 +364,14 @@ class LLMRunner:
             else:
                 self._decode_forward()
                 self._sample_and_advance(guided, guidance_scale, temperature, generator)
+                self._pos_host += 1
             note_position(S_last + 2 + it)
             if logits_log is not None:
                 logits_log.append(self.cfg_logits.clone())
         self.host_enqueue_s = time.perf_counter() - t_enq      # host time to enqueue the loop (< wall time when the GPU is the bound)
-        if self._use_fused and int(self.fused_ctl[1].item()) != 0:
-            raise RuntimeError("ld_llm_decode_blocks_fused: a grid barrier timed out (the persistent decode kernel did not have the "
-                               "GPU to itself?); rerun with fused=False / LD_LLM_FUSED=0")
+        if (self._mode == "fused" and int(self.fused_ctl[1].item()) != 0) or (self._mode == "chained" and int(self.chain_ctl[0].item()) != 0):
+            raise RuntimeError(f"LLM decode ({self._mode}): a device-side wait timed out (the decode did not have the GPU to itself?); "
+                               "rerun with mode='chain' / LD_LLM_DECODE=chain")
         assert int(self.out_count.item()) == n_visual, (int(self.out_count.item()), n_visual)
         out = self.out_tokens[:n_visual]
         if first_frame_tokens is not None:

@@ -301,6 +301,24 @@ def llm_decode_forward_fused(table_dev, n_layers, emb, token, pos, x, qkv, att, 
                                                   _ptr(ctl), _stream()), "ld_llm_decode_forward_fused")
 
 
+LLM_CHAIN_CTL_WORDS = 64 + 256 * 8 * 16     # LD_LLM_CHAIN_CTL_WORDS
+
+
+def llm_decode_blocks_chained(table, pos_value, x, qkv, att, gate, attn_ws, cos_t, sin_t, heads, Lmax, nsplit, rms_eps, ctl, epoch,
+                              stream0, stream1):
+    """All blocks of one decode step as dependent launches alternating between two streams (ld_llm_decode_blocks_chained): the
+    caller orders stream1 after the producers of the KV cache before the first step and the readers of x after both streams."""
+    B, hidden = x.shape
+    for t in (x, qkv, att, gate):
+        assert t.is_contiguous()
+    assert ctl.dtype == torch.int32 and ctl.numel() >= LLM_CHAIN_CTL_WORDS
+    check(_lib.load().ld_llm_decode_blocks_chained(ctypes.addressof(table), len(table), int(pos_value), _ptr(x), _ptr(qkv), _ptr(att),
+                                                   _ptr(gate), _ptr(attn_ws), _ptr(cos_t), _ptr(sin_t), B, hidden, heads,
+                                                   gate.shape[1], Lmax, nsplit, float(rms_eps), _ptr(ctl), int(epoch),
+                                                   ctypes.c_void_p(stream0.cuda_stream), ctypes.c_void_p(stream1.cuda_stream)),
+          "ld_llm_decode_blocks_chained")
+
+
 def llm_logits_to_probs(logits, probs, cfg_logits, guided, scale, temperature, pos=None, allowed=None,
                         top_k=None, top_p=None):
     V = probs.shape[-1]

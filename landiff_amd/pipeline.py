@@ -127,7 +127,7 @@ class LanDiffPipeline:
             with torch.cuda.stream(side):
                 tok = self.llm.sample(inp.llm_text_emb, motion_score=inp.motion_score, num_frames=self.cfg.llm.segment_length,
                                       guidance_scale=inp.cfg, temperature=1.0, seed=inp.seed,
-                                      fused=False).clone()   # (the runner reuses its token buffer; fused=False: runs under the DiT loop)
+                                      mode="chain").clone()   # (the runner reuses its token buffer; mode="chain": the decode runs under the DiT loop)
                 tok.record_stream(main)               # allocated on the side stream, read on the main one: keep the block until that read is done
                 side.synchronize()                    # the tokens are complete before any other stream reads them
             return tok
@@ -214,7 +214,7 @@ class LanDiffPipeline:
                     with torch.cuda.stream(side):
                         self.llm.sample(inp.llm_text_emb, motion_score=inp.motion_score, num_frames=n_seg * lc.segment_length,
                                         guidance_scale=inp.cfg, temperature=1.0, seed=inp.seed, on_segment=on_segment, segment_tokens=per_seg,
-                                        fused=False)
+                                        mode="chain")
                         side.synchronize()
                     decode_state["seconds"] = time.perf_counter() - decode_state["t_start"]
                 except BaseException as e:              # never leave the consumer waiting on a segment that will not come

@@ -12,7 +12,7 @@ cfg = LLMConfig()
 sd = init_state(llm_spec(cfg), 1, dtype=torch.bfloat16, device=dev)
 run = LLMRunner(sd, cfg, dev)
 text = torch.randn(64, cfg.text_dim, device=dev)
-run.sample(text, guidance_scale=7.5, seed=42, num_frames=1, fused=False)       # leaves a filled KV cache and a position
+run.sample(text, guidance_scale=7.5, seed=42, num_frames=1, mode="chain")       # leaves a filled KV cache and a position
 c = cfg
 pos0 = run.pos.clone()
 kc0 = [k.clone() for k in run.kc]; vc0 = [v.clone() for v in run.vc]

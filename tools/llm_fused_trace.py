@@ -15,7 +15,7 @@ sd = init_state(llm_spec(cfg), 1, dtype=torch.bfloat16, device=dev)
 run = LLMRunner(sd, cfg, dev)
 text = torch.randn(64, cfg.text_dim, device=dev)
 run.fused_ctl = torch.zeros(512 + 2 * 12 * 512, device=dev, dtype=torch.int32)
-run.sample(text, guidance_scale=7.5, seed=42, num_frames=2, fused=True)
+run.sample(text, guidance_scale=7.5, seed=42, num_frames=2, mode="fused")
 LABELS = ["qkv: load x + norm", "qkv: batches", "qkv: drain", "barrier 1 (+ wo request)", "attention", "attn: drain", "barrier 2",
           "combine", "comb: drain", "barrier 3", "wo: load x", "wo: batches", "wo: drain", "barrier 4", "w13: load x + norm",
           "w13: batches", "w13: drain", "barrier 5", "w2: load x", "w2: batches", "w2: drain", "barrier 6"]
