@@ -202,7 +202,9 @@ int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, cons
  * ld_llm_embed / ld_gemv / ld_llm_kv_attn / ld_layernorm_bf16_to_f32, queued from native code in one call: the
  * ~150 launches of a step are then bound by the GPU (~1.2 ms) and not by the host language's per-call overhead.
  * emb_table == NULL: x already holds the embedding rows of the token (written by ld_llm_sample_advance).
- * All step state (*token, *pos) is read on the device; buffers are caller-owned: x/att [B][hidden], qkv [B][3*hidden],
+ * All step state (*token, *pos) is read on the device; pos_value >= 0 tells the launches the value *pos holds (a decode loop
+ * knows it: one more per step) so that the attention launches do not start with a dependent load of *pos, -1: read *pos (graph
+ * capture); buffers are caller-owned: x/att [B][hidden], qkv [B][3*hidden],
  * gate [B][mlp] bf16, attn_ws B*heads*(nsplit*130 + 1) words (see ld_llm_kv_attn: the last B*heads zero), lnf_out [B][hidden] fp32,
  * logits [B][vocab] fp32. */
 typedef struct ld_llm_layer {
@@ -211,7 +213,7 @@ typedef struct ld_llm_layer {
   void* k_cache; void* v_cache;                                                        /* bf16 [B][Lmax][heads][128] */
 } ld_llm_layer;
 int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, const float* emb_table, const int64_t* token,
-                          const int32_t* pos, void* x, void* qkv, void* att, void* gate, float* attn_ws,
+                          const int32_t* pos, int32_t pos_value, void* x, void* qkv, void* att, void* gate, float* attn_ws,
                           const float* cos_t, const float* sin_t, const float* lnf_w, const float* lnf_b, float* lnf_out,
                           const float* head_w, float* logits, int64_t B, int64_t hidden, int64_t heads, int64_t mlp,
                           int64_t vocab, int64_t Lmax, int64_t nsplit, float rms_eps, float ln_eps, void* stream);

@@ -73,7 +73,7 @@ SIGNATURES: dict[str, list] = {
     "ld_feature_norm_cl": [P, I32, P, P, P, I64, I64, I64, P],
     "ld_feature_denorm": [P, P, P, P, I64, I64, P],
     "ld_vq_nearest": [P, I64, P, P, I64, I64, I64, P],
-    "ld_llm_decode_forward": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
+    "ld_llm_decode_forward": [P, I64, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
                               c_float, c_float, P],
     "ld_llm_decode_blocks_chained": [P, I64, I32, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_float, P, c_uint32, P, P],
     "ld_llm_decode_blocks_fused": [P, I64, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_float, P, P],

@@ -974,9 +974,20 @@ LD_API int ld_llm_rope_append(const void* qkv, const float* cos_t, const float* 
   return ld_check_launch("ld_llm_rope_append");
 }
 
+static int kv_attn_impl(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, int32_t pos_value, void* out,
+                        int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit,
+                        const void* qkv_fused, const float* cos_t, const float* sin_t, void* stream);
+
 LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
                           int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit,
                           const void* qkv_fused, const float* cos_t, const float* sin_t, void* stream) {
+  return kv_attn_impl(q, k_cache, v_cache, pos, -1, out, B, m, H, Lmax, workspace, nsplit, qkv_fused, cos_t, sin_t, stream);
+}
+
+// pos_value >= 0: the position is known on the host (decode loop): the split launch does not wait for a load of *pos
+static int kv_attn_impl(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, int32_t pos_value, void* out,
+                        int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit,
+                        const void* qkv_fused, const float* cos_t, const float* sin_t, void* stream) {
   LD_REQUIRE(k_cache && v_cache && pos && out, "ld_llm_kv_attn: null pointer");
   LD_REQUIRE(q || qkv_fused, "ld_llm_kv_attn: need q or qkv_fused");
   hipStream_t st = (hipStream_t)stream;
@@ -989,8 +1000,8 @@ LD_API int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cach
     const size_t smem = (chunk + 8 + 4 * 128) * sizeof(float);
     hipLaunchKernelGGL(ld_kv_attn_split_kernel<false>, dim3((unsigned)(B * H), (unsigned)nsplit), dim3(256), smem, st,
                        (const bf16_t*)q, (const bf16_t*)qkv_fused, cos_t, sin_t, (bf16_t*)k_cache, (bf16_t*)v_cache,
-                       (const int*)pos, -1, workspace, (unsigned*)(workspace + B * H * nsplit * 130), (bf16_t*)out, (int)B, (int)H,
-                       (int)Lmax, (int)nsplit, ChainSync{});
+                       (const int*)pos, (int)pos_value, workspace, (unsigned*)(workspace + B * H * nsplit * 130), (bf16_t*)out, (int)B,
+                       (int)H, (int)Lmax, (int)nsplit, ChainSync{});
     return ld_check_launch("ld_llm_kv_attn(split)");
   }
   LD_REQUIRE(q && !qkv_fused, "ld_llm_kv_attn: the fused RoPE/append form exists only for the decode split path");
@@ -1012,7 +1023,7 @@ LD_API int ld_llm_embed(const float* table, const int64_t* token, void* out, int
 }
 
 LD_API int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, const float* emb_table, const int64_t* token,
-                                 const int32_t* pos, void* x, void* qkv, void* att, void* gate, float* attn_ws,
+                                 const int32_t* pos, int32_t pos_value, void* x, void* qkv, void* att, void* gate, float* attn_ws,
                                  const float* cos_t, const float* sin_t, const float* lnf_w, const float* lnf_b,
                                  float* lnf_out, const float* head_w, float* logits, int64_t B, int64_t hidden,
                                  int64_t heads, int64_t mlp, int64_t vocab, int64_t Lmax, int64_t nsplit, float rms_eps,
@@ -1021,6 +1032,7 @@ LD_API int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, c
              lnf_w && lnf_b && lnf_out && head_w && logits, "ld_llm_decode_forward: null pointer");
   LD_REQUIRE(hidden == heads * 128, "ld_llm_decode_forward: head_dim must be 128 (hidden=%ld heads=%ld)", (long)hidden, (long)heads);
   LD_REQUIRE(nsplit > 1, "ld_llm_decode_forward: the decode path is the key-split attention (nsplit > 1)");
+  LD_REQUIRE(pos_value < Lmax, "ld_llm_decode_forward: pos_value %d outside [0, Lmax)", (int)pos_value);
   int rc = emb_table ? ld_llm_embed(emb_table, token, x, B, hidden, stream) : 0;      // null: x already holds the token's embedding rows
   for (int64_t i = 0; i < n_layers && rc == 0; ++i) {
     const ld_llm_layer& w = layers[i];
@@ -1029,7 +1041,7 @@ LD_API int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, c
     rc = ld_gemv(x, hidden, 0, w.wqkv, nullptr, 0, nullptr, nullptr, 0, qkv, 3 * hidden, 0, B, 3 * hidden, hidden, 0, 0,
                  w.n0, rms_eps, stream);
     if (rc) break;
-    rc = ld_llm_kv_attn(nullptr, w.k_cache, w.v_cache, pos, att, B, 1, heads, Lmax, attn_ws, nsplit, qkv, cos_t, sin_t, stream);
+    rc = kv_attn_impl(nullptr, w.k_cache, w.v_cache, pos, pos_value, att, B, 1, heads, Lmax, attn_ws, nsplit, qkv, cos_t, sin_t, stream);
     if (rc) break;
     rc = ld_gemv(att, hidden, 0, w.wo, nullptr, 0, nullptr, x, hidden, x, hidden, 0, B, hidden, hidden, 0, 0, nullptr, 0.f, stream);
     if (rc) break;

@@ -149,6 +149,7 @@ class LLMRunner:
         self._chain_ev = None
         self._chain_epoch = 0
         self._pos_host = 0                 # host mirror of *pos (one more per step)
+        self._capturing = False
 
     # ---- conditioning ------------------------------------------------------------------------
     def _micro_cond(self, frames: float, motion_score: float):
@@ -239,7 +240,8 @@ class LLMRunner:
             return
         ops.llm_decode_forward(self._layer_table, None if self._x_from_tail else self.emb, self.token, self.pos, self.x, self.qkv, self.att, self.gate,
                                self.attn_ws, self.cos, self.sin, self.ln_w, self.ln_b, self.lnf, self.head, self.logits,
-                               c.heads, self.Lmax, self.nsplit, c.rms_eps, c.ln_eps)
+                               c.heads, self.Lmax, self.nsplit, c.rms_eps, c.ln_eps,
+                               pos_value=-1 if self._capturing else self._pos_host)   # (a captured graph must read *pos itself)
 
     def _decode_forward_per_op(self):
         """The same step issued op by op through the C-ABI (kept for tests: must equal _decode_forward bit for bit)."""
@@ -385,9 +387,13 @@ class LLMRunner:
             g.register_generator_state(generator)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            with torch.cuda.graph(g, stream=s):
-                self._decode_forward()
-                self._sample_and_advance(guided, scale, temperature, generator)
+        self._capturing = True
+        try:
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(g, stream=s):
+                    self._decode_forward()
+                    self._sample_and_advance(guided, scale, temperature, generator)
+        finally:
+            self._capturing = False
         torch.cuda.current_stream().wait_stream(s)
         return g

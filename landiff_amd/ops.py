@@ -265,12 +265,12 @@ def llm_layer_table(blocks, k_caches, v_caches):
 
 
 def llm_decode_forward(table, emb, token, pos, x, qkv, att, gate, attn_ws, cos_t, sin_t, lnf_w, lnf_b, lnf_out, head, logits,
-                       heads, Lmax, nsplit, rms_eps, ln_eps):
+                       heads, Lmax, nsplit, rms_eps, ln_eps, pos_value=-1):
     """One decode step (embedding -> all blocks -> final LN -> fp32 head), every launch queued from native code."""
     B, hidden = x.shape
     for t in (x, qkv, att, gate, lnf_out, logits, head):
         assert t.is_contiguous()
-    check(_lib.load().ld_llm_decode_forward(ctypes.addressof(table), len(table), _ptr(emb), _ptr(token), _ptr(pos), _ptr(x),
+    check(_lib.load().ld_llm_decode_forward(ctypes.addressof(table), len(table), _ptr(emb), _ptr(token), _ptr(pos), int(pos_value), _ptr(x),
                                             _ptr(qkv), _ptr(att), _ptr(gate), _ptr(attn_ws), _ptr(cos_t), _ptr(sin_t),
                                             _ptr(lnf_w), _ptr(lnf_b), _ptr(lnf_out), _ptr(head), _ptr(logits), B, hidden,
                                             heads, gate.shape[1], logits.shape[1], Lmax, nsplit, float(rms_eps),
