@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void ld_gemv_reg_kernel(GemvPar
   constexpr int XAUX = CHAIN ? 16 : 0;                 // sc1 on the activation loads
   __shared__ float red[2][4][V];
   __shared__ float ssq[4][B];
-  __shared__ int chain_flag;
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunk = p.K >> 3;
   const int er = tid / B, eb = tid - er * B;          // this thread's epilogue output within a batch: (row er, batch row eb)
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void ld_gemv_reg_kernel(GemvPar
   int batch = blockIdx.x;
   if (CHAIN) {                                         // weights do not depend on the previous operation: request, then wait for it
     request(batch);
-    chain_wait(p.cs, tid, &chain_flag);
+    chain_wait(p.cs, tid);
   }
 #pragma unroll
   for (int b = 0; b < B; ++b) {
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256, CHAIN ? 2 : 1) void ld_kv_attn_split_kernel(co
   KvRows rows;
   if (CHAIN) {
     if (n > 0) kv_rows_request(rows, kc, vc, (long)b * Lmax + k_begin, H, h, n, wave, kq, sub);
-    chain_wait(cs, tid, &is_last);
+    chain_wait(cs, tid);
   }
   if (n == 0) {
     if (tid < D) st_agent(out_ws + 2 + tid, 0.f);

@@ -207,7 +207,7 @@ constexpr int CHAIN_CTR0 = 64, CHAIN_CSTRIDE = 16, CHAIN_NCTR = 8;
 constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 20;
 
 // every thread of the workgroup calls it; one workgroup barrier inside
-__device__ __forceinline__ void chain_wait(const ChainSync& cs, int tid, int* flag) {
+__device__ __forceinline__ void chain_wait(const ChainSync& cs, int tid) {
   if (cs.prev_grid > 0 && tid < 64) {
     const unsigned* ctr = cs.ctl + CHAIN_CTR0 + (cs.slot - 1) * CHAIN_NCTR * CHAIN_CSTRIDE;
     const unsigned mine = tid < CHAIN_NCTR ? cs.epoch1 * (unsigned)((cs.prev_grid - tid + CHAIN_NCTR - 1) / CHAIN_NCTR) : 0u;
@@ -223,7 +223,6 @@ __device__ __forceinline__ void chain_wait(const ChainSync& cs, int tid, int* fl
       }
     }
   }
-  (void)flag;
   __syncthreads();
 }
 
