@@ -36,6 +36,31 @@ def test_argument_validation_without_gpu():
     assert rc < 0 and b"Npad" in lib.ld_last_error()
 
 
+def test_decode_step_forms_validate_without_gpu():
+    """The alternative forms of a decode step's blocks (one persistent launch / dependent launches on two streams) reject null
+    pointers and shapes outside their register forms before any HIP call: LD_ERR_INVALID (-1) / LD_ERR_UNSUPPORTED (-3)."""
+    from landiff_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    fake = [P(4096)] * 9                                            # pos, x, qkv, att, gate, attn_ws, cos, sin (+1): never dereferenced
+    rc = lib.ld_llm_decode_blocks_fused(None, 24, *fake[:8], 2, 2048, 16, 11008, 1762, 8, 1e-5, P(4096), None)
+    assert rc == -1 and b"null" in lib.ld_last_error()
+    rc = lib.ld_llm_decode_blocks_fused(P(4096), 24, *fake[:8], 3, 2048, 16, 11008, 1762, 8, 1e-5, P(4096), None)        # B = 3
+    assert rc == -3 and b"fused form" in lib.ld_last_error()
+    rc = lib.ld_llm_decode_blocks_fused(P(4096), 24, *fake[:8], 2, 4096, 32, 11008, 1762, 8, 1e-5, P(4096), None)        # hidden 4096
+    assert rc == -3
+    table = (_lib.LlmLayer * 1)()
+    args = (ctypes.addressof(table), 1, 5, *fake[:7], 2, 2048, 16, 11008, 1762, 8, 1e-5, P(4096), 0)
+    rc = lib.ld_llm_decode_blocks_chained(*args, P(8), P(8))                                                           # one stream twice
+    assert rc == -1 and b"two different streams" in lib.ld_last_error()
+    rc = lib.ld_llm_decode_blocks_chained(ctypes.addressof(table), 1, 5000, *fake[:7], 2, 2048, 16, 11008, 1762, 8, 1e-5, P(4096), 0, P(8), P(16))
+    assert rc == -1 and b"position" in lib.ld_last_error()
+    rc = lib.ld_llm_decode_blocks_chained(ctypes.addressof(table), 1, 5, *fake[:7], 2, 2048, 16, 20000, 1762, 8, 1e-5, P(4096), 0, P(8), P(16))
+    assert rc == -3 and b"chained form" in lib.ld_last_error()                                                         # mlp 20000
+    rc = lib.ld_llm_decode_blocks_chained(ctypes.addressof(table), 1, 5, *fake[:7], 2, 2048, 16, 11008, 1762, 8, 1e-5, P(4096), 0, P(8), P(16))
+    assert rc == -1 and b"layer 0 has a null pointer" in lib.ld_last_error()                                           # empty layer table entry
+
+
 def test_ops_refuse_cpu_tensors():
     from landiff_amd import _lib, ops
     a = torch.zeros(128, 64, dtype=torch.bfloat16)
