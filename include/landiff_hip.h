@@ -21,7 +21,7 @@ extern "C" {
 /* Bumped whenever a signature changes or an entry point is added / removed (2: ld_groupnorm_stats took its `partials`
  * argument, ld_gemm_qkv_heads / ld_llm_sample_advance / ld_groupnorm_stats_blocks / ld_attn_last_kernel were added).  A caller
  * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does). */
-#define LD_ABI_VERSION 3
+#define LD_ABI_VERSION 4
 
 int ld_version(void);
 const char* ld_last_error(void);
@@ -85,6 +85,12 @@ int ld_gemm_qkv_heads(const void* A, int64_t lda, const void* W, const void* bia
 int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int64_t ldo,
                     int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                     int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, void* stream);
+
+/* Which kernel ld_conv_cl_bf16 runs for a shape, without launching anything (no GPU needed): 0 = 128x128 two-stage,
+ * 1 = 256x256 two-stage (32-bit element offsets: padded inputs up to 8 GiB), 2 = 256x256 8-phase (one raw buffer descriptor
+ * over the padded input: inputs below 2 GiB only -- larger ones are routed to 1), negative = the shape is refused
+ * (e.g. a padded input of 8 GiB or more).  Host logic only; lets the size guard be tested on CPU. */
+int ld_conv_route(int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t kT, int64_t kH, int64_t kW);
 
 /* ---- optional fp8 (OCP e4m3) form of the DiT's large linear layers (BASELINE.json configs[4]; the headline metric and
  * every parity claim of the bf16 path stay on ld_gemm_bf16) ---- */

@@ -1430,7 +1430,22 @@ int launch_w4r(const GemmParams& p, hipStream_t stream) {
   }
 }
 
-int launch(const GemmParams& p, bool conv, hipStream_t stream) {
+// Bytes of the zero-bordered channels-last input a convolution's A-address generator walks: [(T + kT - 1)][Hp][Wp][Cin] bf16.
+long conv_input_bytes(const GemmParams& p) {
+  const long kT = p.K / ((long)p.kH * p.kW * p.Cin);
+  const long T = p.M / ((long)p.H * p.W_);
+  return (T + kT - 1) * p.Hp * p.Wp * p.Cin * 2;
+}
+// The 8-phase kernel addresses a convolution input through ONE raw buffer descriptor based at the tensor (num_records 2^31 - 1,
+// 32-bit per-lane BYTE offsets): inputs of 2 GiB or more are out of its range and take the two-stage kernel, whose 32-bit
+// ELEMENT offsets + 64-bit tap offsets reach 8 GiB (ld_conv_cl_bf16 refuses anything larger).
+constexpr long CONV_8P_MAX_BYTES = 0x7fffffffL;
+constexpr long CONV_MAX_BYTES = 1L << 33;
+
+enum { ROUTE_128_2STAGE = 0, ROUTE_256_2STAGE = 1, ROUTE_256_8PHASE = 2, ROUTE_256_W4R = 3 };
+int g_last_route = -1;          // what launch() picked last (ld_conv_route's dry run reads it)
+
+int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = false) {
   // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves, 3 = 256x256 / 8 waves (both 2-stage, barrier-drained, 16x16x32 MFMAs
   // unless LD_GEMM_M16=0; 3 is the default for large problems when the knob is unset), 11 = 4 waves x 128x128 register-staged
   // on 32x32x16 MFMAs (the round-1 default, kept as the measured alternative; its two siblings -- an 8-wave load/compute
@@ -1456,7 +1471,10 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
     cfg = (tiles256 >= 512 && (conv ? (p.N >= 4096 || p.K >= 4096) : p.K >= 1024)) ? 3 : 1;
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
-  if (cfg != 3 && cfg != 11 && cfg != 8) return launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  if (cfg != 3 && cfg != 11 && cfg != 8) {
+    g_last_route = ROUTE_128_2STAGE;
+    return dry_run ? 0 : launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
+  }
   // default for the large linear layers: the register-staged 4-wave loop (qkv / 4h / 4h->h GEMMs 3-6 % faster than the
   // 8-wave kernel); the gated-residual epilogue on a short K (DiT proj, K = 1920) hides its operand loads better with 8 waves
   // (round 1 default for the large linear layers: the register-staged 4-wave loop on 32x32x16 MFMAs, LD_GEMM_TILE=11; the
@@ -1466,10 +1484,17 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
   static int use8p = -1;
   if (use8p < 0) { const char* e = getenv("LD_GEMM_8P"); use8p = e ? atoi(e) : 1; }
   auto big = [&](const GemmParams& q) {
-    if ((cfg == 8 || use8p) && cfg != 11) return launch_8p(q, conv, stream);
-    if (q.q_out) return launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);      // the fused qkv split lives in the 16x16x32 kernels only
-    if ((cfg == 11 || w4r_default) && pp_ok && !conv) return launch_w4r(q, stream);
-    return launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);
+    const bool conv_in_8p_range = !conv || conv_input_bytes(q) < CONV_8P_MAX_BYTES;
+    if ((cfg == 8 || use8p) && cfg != 11 && conv_in_8p_range) {
+      g_last_route = ROUTE_256_8PHASE;
+      return dry_run ? 0 : launch_8p(q, conv, stream);
+    }
+    if (!q.q_out && (cfg == 11 || w4r_default) && pp_ok && !conv) {
+      g_last_route = ROUTE_256_W4R;
+      return dry_run ? 0 : launch_w4r(q, stream);
+    }
+    g_last_route = ROUTE_256_2STAGE;      // (also the fused qkv split with LD_GEMM_8P=0: it lives in the 16x16x32 kernels only)
+    return dry_run ? 0 : launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);
   };
   // Wave quantisation: one 256x256 tile per CU at a time, so a grid of 4.3 "rounds" of 256 tiles costs 5.  When the last
   // round would be less than ~60 % full, the bottom rows are cut off and run as 128x128 tiles (two per CU, four times as
@@ -1487,7 +1512,7 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream) {
       a.M = rows_main * 256;
       b.m_begin = rows_main * 256;
       const int rc = big(a);
-      if (rc) return rc;
+      if (rc || dry_run) return rc;
       return launch_cfg<128, 128, 2, 2, 2>(b, conv, stream);
     }
   }
@@ -1670,9 +1695,24 @@ LD_API int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int
   p.M = (int)(T * H * W); p.N = (int)Cout; p.K = (int)(kT * kH * kW * Cin); p.lda = 0; p.ldo = ldo;
   p.H = (int)H; p.W_ = (int)W; p.Hp = (int)(H + kH - 1); p.Wp = (int)(W + kW - 1);
   p.Cin = (int)Cin; p.kH = (int)kH; p.kW = (int)kW;
+  LD_REQUIRE(conv_input_bytes(p) < CONV_MAX_BYTES, "ld_conv_cl_bf16: padded input of %ld bytes is beyond the 8 GiB the kernels address "
+             "(split the chunk in time)", conv_input_bytes(p));
   int rc = fill_epilogue(p, epi);
   if (rc) return rc;
   return launch(p, true, (hipStream_t)stream);
+}
+
+LD_API int ld_conv_route(int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t kT, int64_t kH, int64_t kW) {
+  if (T <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || Cin % BK || kT < 1 || kH < 1 || kW < 1 || T * H * W >= (1LL << 31))
+    return ld_set_error(LD_ERR_INVALID, "ld_conv_route: bad shape");
+  GemmParams p{};
+  p.M = (int)(T * H * W); p.N = (int)Cout; p.K = (int)(kT * kH * kW * Cin);
+  p.H = (int)H; p.W_ = (int)W; p.Hp = (int)(H + kH - 1); p.Wp = (int)(W + kW - 1);
+  p.Cin = (int)Cin; p.kH = (int)kH; p.kW = (int)kW;
+  if (conv_input_bytes(p) >= CONV_MAX_BYTES) return ld_set_error(LD_ERR_INVALID, "ld_conv_route: padded input beyond 8 GiB");
+  g_last_route = -1;
+  const int rc = launch(p, true, nullptr, /*dry_run=*/true);
+  return rc ? rc : g_last_route;
 }
 
 LD_API int ld_quantize_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t rows, int64_t K,

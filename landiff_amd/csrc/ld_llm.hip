@@ -679,6 +679,11 @@ __global__ __launch_bounds__(256, CHAIN ? 2 : 1) void ld_kv_attn_split_kernel(co
     kv_attn_split_core(rows, a_q, a_k, a_v, cs_, sn, qkv != nullptr, kc, vc, (long)b * Lmax + pos, H, h, pos - k_begin, n, true,
                        out_ws, red, red + 8, tid, lane, wave, [](float* p, float v) { st_agent(p, v); });
   }
+  // Hand-off in the write-through form (cdna_hip_programming.md section 6 Guideline 16, recipe R1): the partial results were
+  // stored sc1 (st_agent: they leave this XCD's L2), EVERY storing wave drains vmcnt, the workgroup meets, ONE lane arrives
+  // with a relaxed agent-scope add; the last arriver reads the partials with sc1 loads (ld_agent: L1 bypassed), which stand in
+  // for the acquire because the producers stored sc1.  A release/acquire pair on the counter instead would put a
+  // buffer_wbl2 + buffer_inv (~3.5 us, MI355X_MICROARCH.md) into each of the 24 x 1244 launches of a decode.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's part of the partial result is at the coherence point
   __syncthreads();
   if (tid == 0)

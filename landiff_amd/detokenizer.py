@@ -114,13 +114,25 @@ class Detokenizer:
 
     # ---- TiTok decoder --------------------------------------------------------------------
     @torch.no_grad()
+    def index_to_latent(self, tokens: torch.Tensor) -> torch.Tensor:
+        """VideoVQ.index_to_latent (video_titok_vq.py:92-94): tokens int64 [L] on device -> project_out(codebook[tokens]),
+        bf16 [L, token_size]."""
+        codes = self.codebook[tokens.reshape(-1)]                                    # gather (index plumbing)
+        return ops.gemm(codes, self.proj_w, bias=self.proj_b)
+
+    @torch.no_grad()
     def index_to_feature(self, tokens: torch.Tensor) -> torch.Tensor:
         """tokens int64 [L] on device -> features [T, h, w, C] bf16 (channels-last view of [1,T,C,h,w])."""
+        return self.latent_to_feature(self.index_to_latent(tokens))
+
+    @torch.no_grad()
+    def latent_to_feature(self, lat: torch.Tensor) -> torch.Tensor:
+        """TiTokDecoder.forward (tokenizer/modules/blocks.py): latent tokens bf16 [L, token_size] on device -> features
+        [T, h, w, C] bf16 (channels-last view of [1,T,C,h,w])."""
         tc, dev = self.tc, self.dev
         w, N, H = tc.width, self.N, tc.heads
         nv = tc.n_visual
-        codes = self.codebook[tokens.reshape(-1)]                                    # gather (index plumbing)
-        lat = ops.gemm(codes, self.proj_w, bias=self.proj_b)                          # [L, token_size]
+        lat = lat.to(dev, BF).contiguous()
         x0 = torch.empty(N, w, device=dev, dtype=BF)
         x0[:nv] = self.mask_token
         ops.gemm(lat, self.embed_w, out=x0[nv:], bias=self.embed_b)

@@ -250,29 +250,46 @@ class ControlDiTRunner:
         self._linear(self.mlp, lw, "h1", h_out, resid=h_out, gate_off_img=5 * d, gate_off_txt=11 * d, add2=control_add, **gate)
 
     # ---- one denoiser evaluation -----------------------------------------------------------
-    def step(self, x: torch.Tensor, timestep: int, c_out: float, c_skip: float, cfg_scale: float, out: torch.Tensor):
-        """x, out: [1, T, C, H, W] fp32.  out = CFG(denoised_uncond, denoised_cond)."""
+    def _control_chain(self, h_in: torch.Tensor, n_layers: int | None = None):
+        """Control branch: layer l+1 consumes zero_linear_l(layer_l(.)) (SURVEY Appendix C.6,
+        dit_video_concat.py:1224-1238).  h_in [B*N, d] -> self.ctrl_out[0 .. n_layers)."""
         c = self.cfg
-        # control branch: layer l+1 consumes zero_linear_l(layer_l(.)) (SURVEY Appendix C.6)
-        self._time_emb(self.ctrl, timestep)
-        self._embed(self.ctrl, x, self.hc, self.txt_ctrl, self.sem)
-        h_in = self.hc
-        for i in range(c.layers_control):
+        for i in range(c.layers_control if n_layers is None else n_layers):
             self._layer(self.ctrl, i, h_in, self.hc)
             self._timed(2.0 * self.M * c.hidden * c.hidden, ops.gemm, self.hc, self.ctrl.layers[i]["zero_w"], out=self.ctrl_out[i])
             h_in = self.ctrl_out[i]
-        # main branch
-        self._time_emb(self.main, timestep)
-        self._embed(self.main, x, self.h, self.txt_main, None)
-        for i in range(c.layers_main):
+
+    def _main_chain(self, n_layers: int | None = None):
+        """Main branch on self.h in place; layer i < layers_control adds the control state i (dit_video_concat.py:1357-1370)."""
+        c = self.cfg
+        for i in range(c.layers_main if n_layers is None else n_layers):
             self._layer(self.main, i, self.h, self.h, self.ctrl_out[i] if i < c.layers_control else None)
-        m, d, N = self.main, c.hidden, self.N
-        ops.layernorm(self.h, m.fln_w, m.fln_b, self.ln, c.block_ln_eps)
+
+    def _final(self, h: torch.Tensor, x: torch.Tensor, c_out: float, c_skip: float, cfg_scale: float, out: torch.Tensor,
+               sat_final_layernorm: bool = True):
+        """sat's transformer.final_layernorm, then FinalLayerMixin.final_forward (dit_video_concat.py:442-456: adaLN modulation of
+        norm_final over the image tokens, Linear, unpatchify), the denoiser scaling and the CFG combine.  h [B*N, d] bf16;
+        self.emb holds the step's time embedding.  sat_final_layernorm=False starts at final_forward (the seam the reference's
+        own code owns; tests/test_gpu_golden.py feeds it the golden final_in)."""
+        c, m, d, N = self.cfg, self.main, self.cfg.hidden, self.N
+        if sat_final_layernorm:
+            ops.layernorm(h, m.fln_w, m.fln_b, self.ln, c.block_ln_eps)
+            h = self.ln
         ops.gemv(self.emb, m.fada_w, self.fada, bias=m.fada_b, in_act="silu")
-        ops.layernorm(self.ln, m.nf_w, m.nf_b, self.ln, c.final_ln_eps, mod=self.fada, mod_bstride=2 * d, shift_img=0,
+        ops.layernorm(h, m.nf_w, m.nf_b, self.ln, c.final_ln_eps, mod=self.fada, mod_bstride=2 * d, shift_img=0,
                       scale_img=d, shift_txt=0, scale_txt=d, rows_per_batch=N, text_len=0)
         lnv = self.ln.view(self.B, N, d)
         for b in range(self.B):
             ops.gemm(lnv[b, c.text_len:], m.lin_w, out=self.lin[b], bias=m.lin_b)
         ops.unpatchify_cfg(self.lin, x, out, c.patch, c_out, c_skip, cfg_scale)
         return out
+
+    def step(self, x: torch.Tensor, timestep: int, c_out: float, c_skip: float, cfg_scale: float, out: torch.Tensor):
+        """x, out: [1, T, C, H, W] fp32.  out = CFG(denoised_uncond, denoised_cond)."""
+        self._time_emb(self.ctrl, timestep)
+        self._embed(self.ctrl, x, self.hc, self.txt_ctrl, self.sem)
+        self._control_chain(self.hc)
+        self._time_emb(self.main, timestep)
+        self._embed(self.main, x, self.h, self.txt_main, None)
+        self._main_chain()
+        return self._final(self.h, x, c_out, c_skip, cfg_scale, out)

@@ -148,7 +148,7 @@ class LLMRunner:
         self._side = None                  # second stream + event of the chained form
         self._chain_ev = None
         self._chain_epoch = 0
-        self._pos_host = 0                 # host mirror of *pos (one more per step)
+        self._pos_host = -1                # host mirror of *pos, valid only inside sample()'s loop; -1: the kernels read *pos
         self._capturing = False
 
     # ---- conditioning ------------------------------------------------------------------------
@@ -358,18 +358,21 @@ class LLMRunner:
         if use_graph and not debug and steps > 4:
             graph = self._capture(guided, guidance_scale, temperature, generator)
         t_enq = time.perf_counter()
-        for it in range(steps):
-            if teacher_fed is not None:
-                self.token.copy_(teacher_fed[it].reshape(1))
-            if graph is not None:
-                graph.replay()
-            else:
-                self._decode_forward()
-                self._sample_and_advance(guided, guidance_scale, temperature, generator)
-                self._pos_host += 1
-            note_position(S_last + 2 + it)
-            if logits_log is not None:
-                logits_log.append(self.cfg_logits.clone())
+        try:
+            for it in range(steps):
+                if teacher_fed is not None:
+                    self.token.copy_(teacher_fed[it].reshape(1))
+                if graph is not None:
+                    graph.replay()
+                else:
+                    self._decode_forward()
+                    self._sample_and_advance(guided, guidance_scale, temperature, generator)
+                    self._pos_host += 1
+                note_position(S_last + 2 + it)
+                if logits_log is not None:
+                    logits_log.append(self.cfg_logits.clone())
+        finally:
+            self._pos_host = -1            # any other caller of _decode_forward gets the device-side position
         self.host_enqueue_s = time.perf_counter() - t_enq      # host time to enqueue the loop (< wall time when the GPU is the bound)
         if (self._mode == "fused" and int(self.fused_ctl[1].item()) != 0) or (self._mode == "chained" and int(self.chain_ctl[0].item()) != 0):
             raise RuntimeError(f"LLM decode ({self._mode}): a device-side wait timed out (the decode did not have the GPU to itself?); "

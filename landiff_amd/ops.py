@@ -240,6 +240,12 @@ def llm_rope_append(qkv, cos_t, sin_t, pos, q_out, k_cache, v_cache, B, m, H, Lm
 
 def llm_kv_attn(q, k_cache, v_cache, pos, out, B, m, H, Lmax, workspace=None, nsplit=1, qkv_fused=None, cos_t=None,
                 sin_t=None):
+    if workspace is not None and nsplit > 1 and m == 1:
+        # split decode attention: B*H*nsplit partial results of 130 words + one arrival counter per (batch row, head) at the tail,
+        # which must start at zero (the last arriver re-zeroes it) -- include/landiff_hip.h, ld_llm_kv_attn
+        need = B * H * (nsplit * 130 + 1)
+        assert workspace.dtype == torch.float32 and workspace.numel() >= need, \
+            f"ld_llm_kv_attn workspace: {workspace.numel()} fp32 words, needs B*H*(nsplit*130+1) = {need}"
     check(_lib.load().ld_llm_kv_attn(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(pos), _ptr(out), B, m, H, Lmax,
                                      _ptr(workspace), nsplit, _ptr(qkv_fused), _ptr(cos_t), _ptr(sin_t), _stream()),
           "ld_llm_kv_attn")

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/landiff_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.ld_version() == _lib.ABI_VERSION == 3
+    assert lib.ld_version() == _lib.ABI_VERSION == 4
     assert ctypes.sizeof(_lib.Epilogue) == 120          # layout of ld_epilogue_t
 
 
@@ -34,6 +34,26 @@ def test_argument_validation_without_gpu():
     rc = lib.ld_attn_fwd_bf16(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
                               1, 1, 100, 100, 100, 0, 64, 0.125, None, None, None, None, None)
     assert rc < 0 and b"Npad" in lib.ld_last_error()
+
+
+def test_conv_route_keeps_large_inputs_off_the_8_phase_kernel():
+    """The 8-phase kernel walks a convolution's padded input through one raw buffer descriptor (2^31 - 1 records, 32-bit byte
+    offsets): inputs of 2 GiB or more must take the two-stage kernel (32-bit ELEMENT offsets, 8 GiB), and nothing beyond that may
+    launch at all.  ld_conv_route is the launcher's own decision, run dry (no HIP call)."""
+    from landiff_amd import _lib
+    lib = _lib.load()
+    gib = lambda T: (T + 2) * 482 * 722 * 256 * 2 / 2 ** 30
+    # the largest shipped VAE convolution on this route: 9 frames at 480 x 720, Cin = Cout = 256 -- 1.83 GiB, 8-phase
+    assert gib(9) < 2 and lib.ld_conv_route(9, 480, 720, 256, 256, 3, 3, 3) == 2
+    assert gib(10) < 2 and lib.ld_conv_route(10, 480, 720, 256, 256, 3, 3, 3) == 2
+    # one more frame per chunk crosses 2 GiB: same tile, two-stage loop
+    assert gib(11) > 2 and lib.ld_conv_route(11, 480, 720, 256, 256, 3, 3, 3) == 1
+    assert lib.ld_conv_route(45, 480, 720, 256, 256, 3, 3, 3) == 1          # 7.8 GiB: still addressable
+    assert lib.ld_conv_route(47, 480, 720, 256, 256, 3, 3, 3) < 0 and b"8 GiB" in lib.ld_last_error()
+    # narrow / small problems stay on 128 x 128 tiles whatever their size
+    assert lib.ld_conv_route(8, 480, 720, 128, 128, 3, 3, 3) == 0
+    assert lib.ld_conv_route(2, 60, 90, 512, 512, 3, 3, 3) == 0
+    assert lib.ld_conv_route(2, 60, 90, 100, 512, 3, 3, 3) < 0               # Cin must be a multiple of 64
 
 
 def test_decode_step_forms_validate_without_gpu():

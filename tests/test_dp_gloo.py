@@ -119,3 +119,46 @@ def test_rank_core_slices_are_disjoint_and_cover():
     s = [rank_core_slice(r, 4, cores) for r in range(4)]
     assert s == [[0, 1], [2, 3], [8, 9], [10, 11]]
     assert rank_core_slice(0, 1, cores) == cores and rank_core_slice(3, 16, cores) == cores    # fewer cores than ranks: no pinning
+
+
+def _pin_worker(rank, world, q, go):
+    sys.path.insert(0, ROOT)
+    from landiff_amd.pipeline import pin_rank_cores
+    before = sorted(os.sched_getaffinity(0))
+    mine = pin_rank_cores(rank, world)
+    go.wait(timeout=60)                                            # hold the pin until every rank has applied its own
+    import threading
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(sorted(os.sched_getaffinity(0))))     # threads created later inherit the slice
+    t.start(); t.join()
+    q.put((rank, before, list(mine), sorted(os.sched_getaffinity(0)), seen[0], torch.get_num_threads()))
+
+
+def test_eight_ranks_pin_disjoint_core_slices_concurrently():
+    """pin_rank_cores as eight LOCAL ranks of one node run it (bench.py / landiff.infer_video under torchrun): eight live
+    processes at the same time, each reading the cpuset it was started in and cutting its own slice out of it -- the affinity
+    masks the kernel reports back must be pairwise disjoint, lie inside the launch cpuset, be inherited by later threads,
+    and bound torch's intra-op pool.  (With fewer cores than ranks nothing is pinned: every rank keeps the whole set.)"""
+    world = 8
+    cpuset = sorted(os.sched_getaffinity(0))
+    ctx = mp.get_context("spawn")
+    q, go = ctx.Queue(), ctx.Barrier(world)
+    procs = [ctx.Process(target=_pin_worker, args=(r, world, q, go)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r for r, *_ in res] == list(range(world))
+    for rank, before, mine, after, in_thread, nthreads in res:
+        assert before == cpuset                                    # every rank starts from the launch cpuset
+        assert after == in_thread == sorted(mine)                  # what the kernel reports is the slice, in new threads too
+        assert set(after) <= set(cpuset) and 1 <= nthreads <= max(1, len(after))
+    if len(cpuset) >= world:
+        per = len(cpuset) // world
+        masks = [set(after) for _, _, _, after, _, _ in res]
+        assert all(len(m) == per for m in masks)
+        assert all(masks[i].isdisjoint(masks[j]) for i in range(world) for j in range(i + 1, world))
+        assert set().union(*masks) == set(cpuset[: per * world])
+    else:
+        assert all(after == cpuset for _, _, _, after, _, _ in res)

@@ -175,6 +175,55 @@ def test_dit_layer_full_shape_vs_oracle(cuda):
     assert err.mean().item() / ref.abs().mean().item() < 1e-2, (err.mean().item(), ref.abs().mean().item())
 
 
+def test_dit_multi_layer_step_full_shape_vs_oracle(cuda):
+    """A whole denoiser evaluation at the BASELINE shape with the depth cut to 3 control + 3 main layers (B=2 CFG pair, 13 x 30 x 45
+    image tokens + 226 text tokens, hidden 1920): patch / text embedding with the semantic condition added on the control side,
+    the control chain with its zero-linears, three resident control states added into the main chain, sat's final_layernorm,
+    the final adaLN layer, unpatchify, denoiser scaling and the CFG combine -- ControlDiTRunner.step against the fp32 oracle
+    on the host cores (~1 min).  What only appears at this size: the fused qkv launch, persistent 8-phase GEMMs with M-split
+    tails, the 64-row attention tile, workspaces shared across layers while several control states are live."""
+    import dataclasses
+    from landiff_amd.config import PipelineConfig
+    from landiff_amd.dit import ControlDiTRunner
+    from landiff_amd.weights import dit_spec, init_state
+    from oracle.dit import ControlDiTOracle
+    d3 = dataclasses.replace(PipelineConfig.full().dit, layers_main=3, layers_control=3)
+    sd_main, sd_ctrl = init_state(dit_spec(d3, False), 1), init_state(dit_spec(d3, True), 2)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, d3.latent_frames, d3.in_channels, d3.latent_h, d3.latent_w, generator=g)
+    ctx = torch.randn(1, d3.text_len, d3.text_dim, generator=g).to(torch.bfloat16).float()
+    sem = (0.5 * torch.randn(d3.latent_frames, d3.in_channels, d3.latent_h, d3.latent_w, generator=g)).to(torch.bfloat16)
+    timestep, c_out, c_skip, scale = 500, -0.8, 0.6, 4.0
+    run = ControlDiTRunner(sd_main, sd_ctrl, d3, cuda)
+    assert run.fuse_qkv
+    run.set_condition(ctx, sem)
+    outs = {}
+    for s_cfg in (0.0, 1.0, scale):
+        out = torch.empty(1, *x.shape[1:], device=cuda)
+        run.step(x.to(cuda), timestep, c_out, c_skip, s_cfg, out)
+        outs[s_cfg] = out.cpu()
+    out2 = torch.empty(1, *x.shape[1:], device=cuda)
+    run.step(x.to(cuda), timestep, c_out, c_skip, scale, out2)
+    assert torch.equal(out2.cpu(), outs[scale])                       # run-to-run deterministic
+    torch.set_num_threads(min(64, max(torch.get_num_threads(), torch.get_num_threads() * 8)))
+    with torch.no_grad():
+        eps = ControlDiTOracle(sd_main, sd_ctrl, d3, torch.float32)(
+            torch.cat([x, x]), torch.full((2,), float(timestep)), torch.cat([torch.zeros_like(ctx), ctx]), sem.float()).float()
+    den = eps * c_out + torch.cat([x, x]) * c_skip                   # Denoiser.forward: [uncond, cond]
+    ref = {0.0: den[:1], 1.0: den[1:], scale: den[:1] + scale * (den[1:] - den[:1])}
+    for s_cfg, amp in ((0.0, 1.0), (1.0, 1.0), (scale, 2 * scale - 1)):
+        got, r = outs[s_cfg], ref[s_cfg]
+        assert torch.isfinite(got).all()
+        err = (got - r).abs()
+        rng, mean = r.abs().max().item(), r.abs().mean().item()
+        print(f"3+3-layer step, CFG scale {s_cfg}: max err {err.max().item() / rng:.4f} of the range, mean err {err.mean().item() / mean:.4f} of the mean")
+        # seven bf16 layer-calls deep (single layer: <= 3e-2 / 1e-2 above); the CFG combine amplifies rounding noise by 2 s - 1
+        assert err.max().item() / rng < 4e-2 * amp, (s_cfg, err.max().item(), rng)
+        assert err.mean().item() / mean < 1.5e-2 * amp, (s_cfg, err.mean().item(), mean)
+    # the two rows are different problems (text vs zero text): the device must not have mixed them up
+    assert (outs[0.0] - outs[1.0]).abs().mean().item() > 10 * (outs[1.0] - ref[1.0]).abs().mean().item()
+
+
 def test_tokenizer_encoder_full_size_causality(cuda):
     """Full-size encoder (13 x 30 x 45 visual + 1218 latent tokens, 12 layers): the mask's frame causality as a property.
     Changing the features of frames >= f must leave the I tokens (f >= 1) and the P tokens of frames < f bit-identical --
