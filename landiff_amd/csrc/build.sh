@@ -10,7 +10,7 @@ for s in $SRCS; do
   o=obj/${s%.hip}.o
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ ld_common.h -nt "$o" ] || [ ld_attn.h -nt "$o" ] || [ ld_llm_dev.h -nt "$o" ] || [ ../../include/landiff_hip.h -nt "$o" ]; then
     extra=""
-    { [ "$s" = "ld_attn_pipe.hip" ] || [ "$s" = "ld_attn_p16.hip" ] || [ "$s" = "ld_attn_q64.hip" ]; } && extra="-fno-slp-vectorize"
+    { [ "$s" = "ld_attn_pipe.hip" ] || [ "$s" = "ld_attn_p16.hip" ] || [ "$s" = "ld_attn_q64.hip" ] || [ "$s" = "ld_attn_q128.hip" ]; } && extra="-fno-slp-vectorize"
     # the two forms of the decode step (one launch per operation / one persistent launch) must produce the same bits: no
     # implicit mul+add fusion, whose outcome depends on the code around an expression (explicit fmaf / dot2 are unaffected)
     { [ "$s" = "ld_llm.hip" ] || [ "$s" = "ld_llm_fused.hip" ]; } && extra="-ffp-contract=off"

@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
 int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st);   // ld_attn_pipe.hip
 int ld_attn_p16_launch(const AttnParams& p, hipStream_t st);     // ld_attn_p16.hip
 int ld_attn_q64_launch(const AttnParams& p, hipStream_t st);     // ld_attn_q64.hip
+int ld_attn_q128_launch(const AttnParams& p, hipStream_t st);    // ld_attn_q128.hip
 
 // name of the kernel the calling thread's last ld_attn_fwd_bf16 launched (bench.py labels its roofline object with it)
 static thread_local const char* g_attn_last_kernel = "";
@@ -380,6 +381,14 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   const int64_t nkt = (Nk + KT - 1) / KT;
   // LD_ATTN_Q64=0 (tuning knob): the 32-query-row wave tile of ld_attn_p16.hip instead of the 64-row one of ld_attn_q64.hip
   static const int q64 = getenv("LD_ATTN_Q64") ? atoi(getenv("LD_ATTN_Q64")) : 1;
+  // LD_ATTN_Q128 (tuning knob): 1 = the 128-query-row, one-wave-per-SIMD tile of ld_attn_q128.hip (512 rows per workgroup: only
+  // for problems with enough query rows to fill the chip with such workgroups)
+  // for problems with enough query rows to fill the chip with such workgroups; 2: every unmasked problem).  Read on every call
+  // (a getenv is nothing next to a launch) so that one process can time both tiles alternately (tools/attn_ab.py).
+  const char* e128 = getenv("LD_ATTN_Q128");
+  const int q128 = e128 ? atoi(e128) : 0;
+  if (var == 0 && !fid_k && nkt >= 6 && (q128 == 2 || (q128 == 1 && B * H * ((Npad + 511) / 512) >= 512)))
+    return ld_attn_q128_launch(p, st);
   if (var == 0 && !fid_k && nkt >= 6 && q64) return ld_attn_q64_launch(p, st);
   if (var == 0 && !fid_k && nkt >= 6) return ld_attn_p16_launch(p, st);                  // any tile count
   if (var == 8 && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {                              // (the round-1 kernel: tile counts 4 m + 2)

@@ -1,0 +1,489 @@
+// Unmasked DiT attention (joint text+video, head_dim 64) with a 128-query-row wave tile: ONE wave per SIMD, the whole
+// 512-entry register file.  Same reference op (sat attention_fn_default -> F.scaled_dot_product_attention,
+// landiff/diffusion/dit_video_concat.py:636-664), same LDS images, LDS-DMA ring, K-row permutation and max-free fast pass /
+// safe fallback as ld_attn_q64.hip; per 16-query block the arithmetic is the same sequence of MFMAs, exp2 and RNE packs, so the
+// outputs are bit-identical to ld_attn_q64_kernel (tests/test_gpu_attn.py::test_attention_wave_tiles_bit_identical).
+//
+// Why: in ld_attn_q64.hip two waves share a SIMD and every VALU-class issue of one still costs the other half a matrix cycle
+// (profiles/r03_valu_rate_probe.txt).  A wave that owns 128 query rows (eight 16-row blocks qb) feeds EIGHT MFMAs from every
+// K / V^T fragment it reads (four there) and a workgroup of four such waves (512 rows) uses every DMA'd tile for twice the
+// rows: per 72 MFMAs 8 ds_read_b128 and 2 DMA pieces (16 and 4 there), and the 64 v_exp_f32 + 32 v_cvt_pk_bf16_f32 of a half
+// sit in the gaps of the wave's OWN 16-cycle MFMAs -- nothing else issues on that SIMD.
+//
+// Registers.  Everything only the matrix pipe touches lives in the accumulator half of the register file under FIXED names,
+// written literally into the asm text (the compiler's allocator treats a[] as spill space and bounces such values through
+// v_accvgpr_read/write otherwise -- 130 extra VALU-class issues per eight halves in the first build of this file):
+//     a[0:127]    O^T[db][qb]      quad (qb*4 + db)
+//     a[128:191]  Q^T fragments    quad 32 + qb*2 + ks        (pre-scaled by softmax_scale * log2 e)
+//     a[192:207]  K fragments      quad 48 + b*2 + ks         (ds_read_b128 straight into a[])
+//     a[208:223]  V^T fragments    quad 52 + db
+//     a[224:227]  the all-ones A fragment of the row-sum MFMAs
+// The two 64-register score tiles, the packed P (32), the row-sum accumulators (32) and the addresses are ordinary compiler
+// values in the architectural VGPRs, where exp2 and the packs can reach them.  The compiler must not use a[] at all in this
+// kernel: tools/audit_attn_q128.py checks the ISA (no v_accvgpr_* outside the asm blocks, no scratch in the loop) and
+// tests/test_cabi_and_host.py runs it.
+//
+// What hipcc does not do for these asm statements, and where it is taken care of (cdna_hip_programming.md 5.7):
+//   * ds_read_b128 into a[] is not counted: s_waitcnt lgkmcnt(0) by hand in front of the first MFMA of the phase that uses
+//     the fragments (they were requested >= 20 MFMAs earlier; nothing else of this wave is on the lgkm counter in the loop).
+//   * an MFMA's result is not interlocked against VALU readers: every score is read >= 16 MFMA issues after the MFMA that
+//     produced it (phase structure below); the mask path, the end of the loop and the epilogue pad with s_nop.
+//   * v_accvgpr_write -> MFMA and VALU -> MFMA-operand wait states: the writes happen in the prologue, the packs of P at least
+//     one MFMA before the PV MFMA that reads them.
+//
+// Pipeline on HALF tiles (32 keys), as in ld_attn_q64.hip with everything doubled:
+//   phase 1: QK^T of half h+1 (32 MFMAs) over exp2 of scores NPRE..63 of half h, the 32 packs, 4 V^T fragment reads, 2 DMA pieces
+//   phase 2: PV + row sums of half h (40 MFMAs) over exp2 of scores 0..NPRE-1 of half h+1 and the 4 K fragment reads of half h+2
+// LDS ring and barrier cadence unchanged: four K and four V^T slots of 8 KB, one workgroup barrier per two tiles.
+#include "ld_attn.h"
+
+namespace {
+
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ int q128_swz_k(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+
+constexpr int Q128_NW = 4;                 // waves per workgroup
+constexpr int Q128_NQB = 8;                // 16-row query blocks per wave
+constexpr int Q128_WROWS = Q128_NQB * 16;  // query rows per wave
+constexpr int Q128_ROWS = Q128_NW * Q128_WROWS;
+
+// first register of the fixed quads
+constexpr int AO(int db, int qb) { return (qb * 4 + db) * 4; }
+constexpr int AQ(int qb, int ks) { return 128 + (qb * 2 + ks) * 4; }
+constexpr int AK(int bb, int ks) { return 192 + (bb * 2 + ks) * 4; }
+constexpr int AV(int db) { return 208 + db * 4; }
+constexpr int Q128_AGPRS = 228;
+
+template <int I> using IC = std::integral_constant<int, I>;
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(IC<I>{}); static_for<N, I + 1>(f); }
+}
+
+// S^T quad (VGPRs)  = / +=  K fragment (a[K:K+3]) . Q^T fragment (a[Q:Q+3])
+template <int K, int Q> __device__ __forceinline__ void mfma_s_zero(f32x4_t& d) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(d) : "i"(K), "i"(K + 3), "i"(Q), "i"(Q + 3));
+}
+template <int K, int Q> __device__ __forceinline__ void mfma_s_acc(f32x4_t& d) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(d) : "i"(K), "i"(K + 3), "i"(Q), "i"(Q + 3));
+}
+// O^T quad (a[O:O+3]) += V^T fragment (a[V:V+3]) . P fragment (VGPRs)
+template <int O, int V> __device__ __forceinline__ void mfma_o(const u32x4_t& pw) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], a[%c2:%c3], %4, a[%c0:%c1]" :: "i"(O), "i"(O + 3), "i"(V), "i"(V + 3), "v"(pw));
+}
+// l quad (VGPRs) += ones (a[224:227]) . P fragment.  The all-ones fragment is pinned too: as a compiler value it is re-materialised
+// by two v_mov_b64 directly in front of the MFMA, and nothing pads the VALU-write -> MFMA-operand-read wait states around an asm
+// statement (the first hardware runs of this kernel had wrong denominators for exactly that reason).
+constexpr int AONES = 224;
+__device__ __forceinline__ void mfma_l(f32x4_t& d, const u32x4_t& pw) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], %3, %0" : "+v"(d) : "i"(AONES), "i"(AONES + 3), "v"(pw));
+}
+template <int A, int OFF> __device__ __forceinline__ void lds_to_acc(uint32_t addr) {      // a[A:A+3] <- LDS[addr + OFF .. + 16)
+  asm volatile("ds_read_b128 a[%c0:%c1], %2 offset:%c3" :: "i"(A), "i"(A + 3), "v"(addr), "i"(OFF) : "memory");
+}
+template <int A> __device__ __forceinline__ void acc_write4(const u32x4_t& v) {
+  asm volatile("v_accvgpr_write_b32 a[%c0], %4\n\tv_accvgpr_write_b32 a[%c1], %5\n\tv_accvgpr_write_b32 a[%c2], %6\n\tv_accvgpr_write_b32 a[%c3], %7"
+               :: "i"(A), "i"(A + 1), "i"(A + 2), "i"(A + 3), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+}
+template <int A> __device__ __forceinline__ f32x4_t acc_read4() {
+  f32x4_t r;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+               : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : "i"(A), "i"(A + 1), "i"(A + 2), "i"(A + 3));
+  return r;
+}
+// exp2 and the RNE pack as pinned statements: as plain expressions they are free-floating DAG nodes between the (side-effecting)
+// asm MFMAs, and hipcc sinks all 32 packs of a half in front of the first PV MFMA -- a 32-instruction VALU block with the
+// matrix pipe idle.  Same instructions the compiler emits for __builtin_amdgcn_exp2f / the bf16 conversion.
+__device__ __forceinline__ void exp2_inplace(float& x) { asm volatile("v_exp_f32 %0, %0" : "+v"(x)); }
+__device__ __forceinline__ uint32_t pack_pinned(float lo, float hi) {
+  uint32_t r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }    // > the 8-pass MFMA's result latency
+__device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int NPRE>
+__device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_safe, char* smem) {   // smem: K slots 0..3 | V^T slots 0..3 | flag words
+  constexpr int NW = Q128_NW, NQB = Q128_NQB;
+  constexpr int VBASE = 4 * KTILE_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, h4 = lane >> 4;
+  constexpr int NPW = 16 / NW;                    // LDS-DMA pieces per wave and tile
+  const int nqb = (p.Npad + Q128_ROWS - 1) / Q128_ROWS;
+  const int n = (p.Nk + KT - 1) / KT;             // >= 6 (launcher)
+  const int NH = 2 * n;                           // halves
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = bid / nqb, qblk = bid - bh * nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const bf16_t* Qb = p.Q + (long)bh * p.Npad * D;
+  const bf16_t* Kb = p.K + (long)bh * p.Npad * D;
+  const bf16_t* Vb = p.Vt + (long)bh * D * p.Npad;
+  const int q0 = qblk * Q128_ROWS + wave * Q128_WROWS;
+  if (qblk * Q128_ROWS >= p.Nq) return;
+
+  // Q^T fragments (B operand): rows q0 + qb*16 + l16, d = ks*32 + h4*8 .. + 8, pre-multiplied by scale * log2(e) -> a[128:191]
+  static_for<NQB>([&](auto qc) {
+    constexpr int qb = decltype(qc)::value;
+    const int q = q0 + qb * 16 + l16;
+    const bf16_t* qrow = Qb + (long)(q < p.Npad ? q : p.Npad - 1) * D + h4 * 8;
+    static_for<2>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      const u32x4_t raw = *(const u32x4_t*)(qrow + ks * 32);
+      u32x4_t sc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[e] = pack_bf16x2(bf_lo(raw[e]) * p.c, bf_hi(raw[e]) * p.c);
+      acc_write4<AQ(qb, ks)>(sc);
+    });
+  });
+
+  // LDS-DMA: waves 0, 1 bring K tiles (rows = keys), waves 2, 3 V^T tiles (rows = d)
+  const bool kwave = wave < NW / 2;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(kwave ? Kb : Vb), 0, 0x7fffffff, 0x00020000);   // raw buffer, wave-uniform
+  const int tstride = kwave ? KT * D * 2 : KT * 2;               // bytes per tile step in the source
+  const int rstride = kwave ? D : p.Npad;
+  uint32_t goff[NPW];
+  int ldsoff[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int piece = (wave % (NW / 2)) * NPW + i;
+    const int r = piece * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (kwave ? q128_swz_k(r) : ((r >> 1) & 7));
+    goff[i] = (uint32_t)(r * rstride + chunk * 8) * 2u;
+    ldsoff[i] = (kwave ? 0 : VBASE) + piece * 1024;
+  }
+  auto dma_piece = [&](int i, int slot, int t) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + slot * KTILE_BYTES + ldsoff[i]),
+                                             16, goff[i], t * tstride, 0, 0);
+  };
+  auto dma = [&](int slot, int t) {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) dma_piece(i, slot, t);
+  };
+
+  // fragment read addresses (LDS byte addresses): K block 2*kg + b, k-step ks: kaddr[ks] + slot*8K + kg*4096 + b*512;
+  // V^T block db, key group kg: vaddr[kg] + VBASE + slot*8K + db*2048
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t kaddr[2], vaddr[2];
+  {
+    const int key = 8 * (l16 >> 2) + (l16 & 3);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 4 + h4;
+      kaddr[ks] = lds0 + key * 128 + ((c ^ q128_swz_k(key)) << 4);
+      vaddr[ks] = lds0 + l16 * 128 + ((c ^ ((l16 >> 1) & 7)) << 4);
+    }
+  }
+  // fragment loads into the fixed quads: slot / key group are compile-time (they go into the offset field)
+  auto KF = [&](auto slot_c, auto kg_c, auto g_c) {              // g = b*2 + ks
+    constexpr int slot = decltype(slot_c)::value, kg = decltype(kg_c)::value, g = decltype(g_c)::value;
+    lds_to_acc<AK(g >> 1, g & 1), slot * KTILE_BYTES + kg * 4096 + (g >> 1) * 512>(kaddr[g & 1]);
+  };
+  auto VF = [&](auto slot_c, auto kg_c, auto db_c) {
+    constexpr int slot = decltype(slot_c)::value, kg = decltype(kg_c)::value, db = decltype(db_c)::value;
+    lds_to_acc<AV(db), VBASE + slot * KTILE_BYTES + db * 2048>(vaddr[kg]);
+  };
+  // S^T of one half from the K fragments in a[192:207]: g = ks*16 + b*8 + qb
+  auto QK = [&](f32x4_t (&s)[2][NQB], auto g_c) {
+    constexpr int g = decltype(g_c)::value;
+    constexpr int ks = g >> 4, bb = (g >> 3) & 1, qb = g & 7;
+    if constexpr (ks == 0) mfma_s_zero<AK(bb, 0), AQ(qb, 0)>(s[bb][qb]);
+    else mfma_s_acc<AK(bb, 1), AQ(qb, 1)>(s[bb][qb]);
+  };
+
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto zero_o = [&]() {
+    const u32x4_t z = {0u, 0u, 0u, 0u};
+    static_for<32>([&](auto c) { acc_write4<decltype(c)::value * 4>(z); });
+  };
+
+  // keys of half hh (tile hh >> 1, key group hh & 1) past Nk -> -inf-like scores
+  auto mask_half = [&](f32x4_t (&s)[2][NQB], int hh) {
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int key0 = (hh >> 1) * KT + (hh & 1) * 32 + h4 * 8 + bb * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (key0 + r >= p.Nk) {
+#pragma unroll
+          for (int qb = 0; qb < NQB; ++qb) s[bb][qb][r] = NEG_BIG;
+        }
+    }
+  };
+
+  // ---------------- fast pass: no running maximum (see ld_attn_pipe.hip for the argument and the window test) ----------------
+  float ltot[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) ltot[qb] = 0.f;
+  auto fast_pass = [&]() {
+    f32x4_t lacc[NQB];                                          // softmax denominators from the matrix pipe: ones(16 x 32) . P[qb]
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) lacc[qb] = zero4;
+    zero_o();
+    acc_write4<AONES>((u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    f32x4_t sA[2][NQB], sB[2][NQB];
+    // the 64 scores of a lane in a half are numbered v = b*32 + qb*4 + r
+    auto EXPV = [&](f32x4_t (&s)[2][NQB], int v) { const int bb = v >> 5, qb = (v >> 2) & 7, r = v & 3; float x = s[bb][qb][r]; exp2_inplace(x); s[bb][qb][r] = x; };
+
+    // One pipelined iteration on half hh (phase PH = hh & 7 fixes every slot).  sc = S_hh (the first NPRE already probabilities),
+    // sn receives S_{hh+1}; the K fragments of half hh+2 are fetched and this half's share of the period's DMA pieces issued
+    // (past the end the tile index is clamped: a re-fetch of the last tile); mask: half hh+1 holds keys past Nk (possibly all).
+    auto iter = [&](f32x4_t (&sc)[2][NQB], f32x4_t (&sn)[2][NQB], int hh, auto phase_c, bool mask) {
+      constexpr int PH = decltype(phase_c)::value;
+      constexpr int kg = PH & 1;
+      constexpr int vslot = (PH >> 1) & 3;                       // slot of this half's tile
+      constexpr int k2slot = ((PH + 2) >> 1) & 3;                // slot of the tile of half hh + 2 (same key group kg)
+      constexpr int PER = PH & 3;                                // position inside the period (two tiles)
+      constexpr int pslot = vslot & 2;                           // slot of the period's first tile
+      const int tp = (hh >> 1) - ((PH >> 1) & 1);                // the period's first tile
+      int dt0 = kwave ? tp + 3 : tp + 2, dt1 = dt0 + 1;
+      dt0 = dt0 < n ? dt0 : n - 1; dt1 = dt1 < n ? dt1 : n - 1;
+      constexpr int kslot0 = (pslot + 3) & 3, kslot1 = pslot, vslot0 = (pslot + 2) & 3, vslot1 = (pslot + 3) & 3;
+      const int dslot0 = kwave ? kslot0 : vslot0, dslot1 = kwave ? kslot1 : vslot1;
+      u32x4_t pw[NQB];                                            // P fragments [qb]
+      auto CW = [&](int w) {                                      // packed word w = qb*4 + b*2 + half of the P fragments
+        const int qb = w >> 2, bb = (w >> 1) & 1, hf = w & 1;
+        pw[qb][2 * bb + hf] = pack_pinned(sc[bb][qb][2 * hf], sc[bb][qb][2 * hf + 1]);
+      };
+      auto DMA = [&](int i) {                 // piece 2 * PER + i of the period's 2 * NPW
+        constexpr int g0 = 2 * PER;
+        const int g = g0 + i;
+        dma_piece(g % NPW, g < NPW ? dslot0 : dslot1, g < NPW ? dt0 : dt1);
+      };
+      // ---- phase 1: QK^T of half hh+1 (32 MFMAs, g = ks*16 + b*8 + qb) over exp2 of scores NPRE..63 of half hh, the packing
+      //      of P (one packed word per gap, word qb*4 + b*2 + half in gap of the same number: its scores are finished by then), the
+      //      V^T fragment reads of half hh and this half's two DMA pieces ----
+      lgkm_wait0();                                               // the K fragments requested in the previous phase 2
+      static_for<32>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        QK(sn, gc);
+        if constexpr (NPRE + g < 64) EXPV(sc, NPRE + g);
+        CW(g);                                                    // (its two scores were exponentiated >= 3 gaps ago: NPRE >= 36)
+        if constexpr (g == 1) DMA(0);
+        if constexpr (g == 5) DMA(1);
+        if constexpr (g == 3) VF(IC<vslot>{}, IC<kg>{}, IC<0>{});
+        if constexpr (g == 7) VF(IC<vslot>{}, IC<kg>{}, IC<1>{});
+        if constexpr (g == 9) VF(IC<vslot>{}, IC<kg>{}, IC<2>{});
+        if constexpr (g == 11) VF(IC<vslot>{}, IC<kg>{}, IC<3>{});
+        FENCE();
+      });
+      if (mask) {
+        mfma_settle();                                            // the last QK^T MFMAs must have written sn before VALU touches it
+        mask_half(sn, hh + 1);
+      }
+      // ---- phase 2: PV and row sums of half hh (per query block: 4 PV + 1 row-sum MFMA) over exp2 of scores 0..NPRE-1 of half
+      //      hh+1 (spread evenly over the 40 gaps) and the K fragment reads of half hh+2 ----
+      lgkm_wait0();                                               // the V^T fragments requested in phase 1
+      static_for<40>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int qb = g / 5, j = g - qb * 5;
+        if constexpr (j < 4) mfma_o<AO(j, qb), AV(j)>(pw[qb]);
+        else mfma_l(lacc[qb], pw[qb]);
+        static_for<(g + 1) * NPRE / 40 - g * NPRE / 40>([&](auto ec) { EXPV(sn, g * NPRE / 40 + decltype(ec)::value); });
+        if constexpr (g == 0) KF(IC<k2slot>{}, IC<kg>{}, IC<0>{});
+        if constexpr (g == 2) KF(IC<k2slot>{}, IC<kg>{}, IC<1>{});
+        if constexpr (g == 4) KF(IC<k2slot>{}, IC<kg>{}, IC<2>{});
+        if constexpr (g == 6) KF(IC<k2slot>{}, IC<kg>{}, IC<3>{});
+        FENCE();
+      });
+      // ---- end of a period: retire this wave's LDS reads and DMA pieces, then the barrier ----
+      if (PER == 3) {
+        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+      }
+      FENCE();
+    };
+
+    // ---- prologue: K0..K2, V0, V1 land; S_0 from K0 key group 0; the K fragments of half 1 ----
+    if (kwave) { dma(0, 0); dma(1, 1); dma(2, 2); }
+    else { dma(0, 0); dma(1, 1); }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    FENCE();
+    static_for<4>([&](auto gc) { KF(IC<0>{}, IC<0>{}, gc); });
+    lgkm_wait0();
+    static_for<32>([&](auto gc) { QK(sA, gc); });
+    FENCE();
+    static_for<4>([&](auto gc) { KF(IC<0>{}, IC<1>{}, gc); });     // (issued behind the MFMAs that read the quads: in order on this wave)
+    mfma_settle();
+#pragma unroll
+    for (int v = 0; v < NPRE; ++v) EXPV(sA, v);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();        // every wave has K0's fragments in registers: period 0 may refill its slot
+    FENCE();
+
+    // ---- the loop: eight halves (four tiles) per trip over ALL halves rounded up to a multiple of eight, halves past the end
+    //      masked to exactly-zero probabilities (see ld_attn_q64.hip); the trips that need no mask run without mask tests ----
+    const int hmask = p.Nk / 32;                    // first half that holds a key >= Nk
+    int hh = 0;
+    for (; hh + 8 < hmask; hh += 8) {
+      iter(sA, sB, hh,     IC<0>{}, false);
+      iter(sB, sA, hh + 1, IC<1>{}, false);
+      iter(sA, sB, hh + 2, IC<2>{}, false);
+      iter(sB, sA, hh + 3, IC<3>{}, false);
+      iter(sA, sB, hh + 4, IC<4>{}, false);
+      iter(sB, sA, hh + 5, IC<5>{}, false);
+      iter(sA, sB, hh + 6, IC<6>{}, false);
+      iter(sB, sA, hh + 7, IC<7>{}, false);
+    }
+    for (; hh < NH; hh += 8) {                      // the last one or two trips
+      iter(sA, sB, hh,     IC<0>{}, hh + 1 >= hmask);
+      iter(sB, sA, hh + 1, IC<1>{}, hh + 2 >= hmask);
+      iter(sA, sB, hh + 2, IC<2>{}, hh + 3 >= hmask);
+      iter(sB, sA, hh + 3, IC<3>{}, hh + 4 >= hmask);
+      iter(sA, sB, hh + 4, IC<4>{}, hh + 5 >= hmask);
+      iter(sB, sA, hh + 5, IC<5>{}, hh + 6 >= hmask);
+      iter(sA, sB, hh + 6, IC<6>{}, hh + 7 >= hmask);
+      iter(sB, sA, hh + 7, IC<7>{}, hh + 8 >= hmask);
+    }
+    mfma_settle();                                  // the last row-sum / PV MFMAs have written their accumulators
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) ltot[qb] = lacc[qb][0];
+  };
+
+  // ---------------- safe pass: plain online softmax with a running maximum, one half tile at a time (the fallback; not tuned).
+  // O^T stays in a[0:127]: a rescale reads, multiplies and writes back the query block's four quads ----------------
+  auto safe_pass = [&]() {
+    float m[NQB], ls[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) { m[qb] = NEG_BIG; ls[qb] = 0.f; }
+    zero_o();
+    auto half = [&](int t, auto kg_c) {
+      constexpr int kg = decltype(kg_c)::value;
+      f32x4_t s[2][NQB];
+      static_for<4>([&](auto gc) { KF(IC<0>{}, kg_c, gc); });
+      static_for<4>([&](auto dc) { VF(IC<0>{}, kg_c, dc); });
+      lgkm_wait0();
+      static_for<32>([&](auto gc) { QK(s, gc); });
+      mfma_settle();
+      if ((t + 1) * KT > p.Nk) mask_half(s, 2 * t + kg);
+      static_for<NQB>([&](auto qc) {
+        constexpr int qb = decltype(qc)::value;
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[bb][qb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m[qb], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+        m[qb] = mn;
+        ls[qb] *= alpha;
+        static_for<4>([&](auto dc) {
+          constexpr int db = decltype(dc)::value;
+          f32x4_t o4 = acc_read4<AO(db, qb)>();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o4[r] *= alpha;
+          acc_write4<AO(db, qb)>(__builtin_bit_cast(u32x4_t, o4));
+        });
+        u32x4_t pw;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s[bb][qb][r] = __builtin_amdgcn_exp2f(s[bb][qb][r] - mn); ls[qb] += s[bb][qb][r]; }
+          pw[2 * bb] = pack_bf16x2(s[bb][qb][0], s[bb][qb][1]);
+          pw[2 * bb + 1] = pack_bf16x2(s[bb][qb][2], s[bb][qb][3]);
+        }
+        asm volatile("s_nop 4" ::: "memory");                     // v_accvgpr_write / v_cvt_pk -> MFMA operand wait states
+        static_for<4>([&](auto dc) { mfma_o<AO(decltype(dc)::value, qb), AV(decltype(dc)::value)>(pw); });
+        mfma_settle();                                            // (the next block's rescale reads other quads, but keep it simple)
+      });
+    };
+    for (int t = 0; t < n; ++t) {
+      __syncthreads();                                 // every wave is done with slot 0 of the previous tile
+      dma(0, t);                                       // K waves: K_t -> K slot 0; V waves: V_t -> V slot 0
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      __syncthreads();
+      half(t, IC<0>{});
+      half(t, IC<1>{});
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      float l = ls[qb];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      ltot[qb] = l;
+    }
+  };
+
+  bool redo = force_safe != 0;
+  if (!redo) {
+    fast_pass();
+    // 2^-80 <= l <= 2^110 (NaN fails): see the header comment of ld_attn_pipe.hip
+    bool bad = false;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+      bad = bad || (!(ltot[qb] >= 8.2718061e-25f && ltot[qb] <= 1.2980742e33f) && (q0 + qb * 16 + l16 < p.Nq));
+    int* flags = (int*)(smem + 8 * KTILE_BYTES);
+    const bool wbad = __any(bad);
+    if (lane == 0) flags[wave] = wbad ? 1 : 0;
+    __syncthreads();
+    redo = false;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) redo = redo || flags[w] != 0;
+    __syncthreads();
+  }
+  if (redo) safe_pass();
+
+  mfma_settle();
+  static_for<NQB>([&](auto qc) {
+    constexpr int qb = decltype(qc)::value;
+    const int q = q0 + qb * 16 + l16;
+    const float inv = ltot[qb] > 0.f ? 1.0f / ltot[qb] : 0.f;
+    bf16_t* orow = p.O + (long)b * p.o_bs + (long)q * p.o_rs + h * D + h4 * 4;
+    static_for<4>([&](auto dc) {
+      constexpr int db = decltype(dc)::value;
+      const f32x4_t o4 = acc_read4<AO(db, qb)>();
+      u32x2_t w2;
+      w2[0] = pack_bf16x2(o4[0] * inv, o4[1] * inv);
+      w2[1] = pack_bf16x2(o4[2] * inv, o4[3] * inv);
+      if (q < p.Nq) *(u32x2_t*)(orow + db * 16) = w2;
+    });
+  });
+}
+#undef FENCE
+
+// The kernel descriptor must cover a[0:227]: the compiler only counts registers it sees, so the entry names the last one.
+// NPRE (scores of the next half exponentiated under the PV phase): 36 is ld_attn_q64.hip's split doubled; larger values move
+// exp2 issues from the QK^T gaps (MFMA + exp2 + pack) into the PV gaps (MFMA + exp2).
+#define LD_Q128_KERNEL(NAME, NPRE_)                                                                       \
+  __global__ __launch_bounds__(256, 1) void NAME(AttnParams p, int force_safe) {                          \
+    extern __shared__ __attribute__((aligned(16))) char smem[];                                           \
+    asm volatile("; ld_attn_q128: a[0:227] are owned by the asm statements of this kernel" ::: "a0", "a227"); \
+    attn_q128_body<NPRE_>(p, force_safe, smem);                                                           \
+  }
+LD_Q128_KERNEL(ld_attn_q128_kernel, 44)
+LD_Q128_KERNEL(ld_attn_q128_n36_kernel, 36)
+LD_Q128_KERNEL(ld_attn_q128_n52_kernel, 52)
+
+}  // namespace
+
+void ld_attn_set_last_kernel(const char* name);   // ld_attn.hip
+
+// LD_ATTN_SAFE=1 forces the running-max pass (testing); LD_ATTN_NPRE=36|52 picks the other exp2 splits (A/B timing).
+int ld_attn_q128_launch(const AttnParams& p, hipStream_t st) {
+  constexpr int SMEM = 8 * KTILE_BYTES + 64;
+  static int safe = -1;
+  if (safe < 0) { const char* e = getenv("LD_ATTN_SAFE"); safe = e ? atoi(e) : 0; }
+  const char* ne = getenv("LD_ATTN_NPRE");            // per call, like LD_ATTN_Q128 (ld_attn.hip)
+  const int npre = ne ? atoi(ne) : 44;
+  static thread_local LdSmemCache c44{}, c36{}, c52{};
+  dim3 grid((unsigned)((long)p.B * p.H * ((p.Npad + Q128_ROWS - 1) / Q128_ROWS)));
+  if (npre == 36 || npre == 52) {
+    auto k = npre == 36 ? ld_attn_q128_n36_kernel : ld_attn_q128_n52_kernel;
+    if (int rc = ld_ensure_dyn_smem((const void*)k, SMEM, npre == 36 ? &c36 : &c52)) return rc;
+    ld_attn_set_last_kernel(npre == 36 ? "ld_attn_q128_n36_kernel" : "ld_attn_q128_n52_kernel");
+    hipLaunchKernelGGL(k, grid, dim3(256), SMEM, st, p, safe);
+    return ld_check_launch("ld_attn_fwd_bf16(q128)");
+  }
+  if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_q128_kernel, SMEM, &c44)) return rc;
+  ld_attn_set_last_kernel(safe ? "ld_attn_q128_kernel[safe pass forced]" : "ld_attn_q128_kernel");
+  hipLaunchKernelGGL(ld_attn_q128_kernel, grid, dim3(256), SMEM, st, p, safe);
+  return ld_check_launch("ld_attn_fwd_bf16(q128)");
+}

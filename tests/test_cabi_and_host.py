@@ -281,3 +281,17 @@ def test_save_video_tensor_fallback_writes_playable_avi(tmp_path):
         assert img.shape == (H, W, 3) and np.abs(img.astype(int) - frames[n].astype(int)).mean() < 4.0
         pos += 8 + size + (size & 1); n += 1
     assert n == T and raw[pos:pos + 4] == b"idx1"
+
+
+def test_attention_q128_isa_audit():
+    """ld_attn_q128.hip owns a[0:223] by name: the build must not spill, and the compiler must not emit a single accumulator-
+    register access of its own in that kernel; the hot loop must hold the instruction mix it was written for, the exp2 / pack
+    work interleaved with the MFMAs (tools/audit_attn_q128.py rebuilds the file with -save-temps and reads the ISA)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("audit_attn_q128", os.path.join(ROOT, "tools", "audit_attn_q128.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        report = mod.audit(mod.build(tmp))
+    assert len(report) == 3 and all("no compiler a[] traffic" in r for r in report)

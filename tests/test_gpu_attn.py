@@ -88,3 +88,50 @@ def test_attn_frame_mask(cuda):
     T, tpf, nI, nP = 5, 90, 22, 7
     fid = np.concatenate([np.repeat(np.arange(T), tpf), np.zeros(nI, np.int64), np.repeat(np.arange(1, T), nP)]).astype(np.int32)
     assert _run(cuda, 1, 2, len(fid), fid=fid, seed=3) < 2e-2
+
+
+# ---- the 128-query-row / one-wave-per-SIMD tile (ld_attn_q128.hip; LD_ATTN_Q128 is read on every call) ----
+@pytest.fixture
+def q128(monkeypatch):
+    monkeypatch.setenv("LD_ATTN_Q128", "2")        # 2: every unmasked problem of >= 6 key tiles, whatever its size
+
+
+def _last_kernel():
+    from landiff_amd import _lib
+    return (_lib.load().ld_attn_last_kernel() or b"").decode()
+
+
+@pytest.mark.parametrize("B,H,N", [(1, 2, 1122), (2, 1, 1400), (1, 1, 2175), (1, 1, 1152), (1, 1, 384), (1, 1, 385), (1, 2, 448),
+                                   (1, 1, 500), (1, 1, 512), (2, 1, 575), (1, 1, 640), (1, 1, 700), (1, 1, 768), (1, 1, 830),
+                                   (1, 3, 2600)])       # 2600: two full 512-row workgroups per head + ragged rows in every wave of the last
+def test_attn_q128_tile(cuda, q128, B, H, N):
+    assert _run(cuda, B, H, N, seed=N) < 2e-2
+    assert _last_kernel() == "ld_attn_q128_kernel"
+
+
+def test_attn_q128_spike_and_overflow_fallback(cuda, q128):
+    assert _run(cuda, 1, 2, 1400, spike=True, relative=True) < 1e-2
+    err = _run(cuda, 1, 2, 1122, spike=True, q_scale=6.0, relative=True)      # the fast pass must notice and redo with the running max
+    assert err == err and err < 0.2
+    assert _last_kernel() == "ld_attn_q128_kernel"
+
+
+def test_attn_q128_equals_q64_bit_for_bit_in_process(cuda, monkeypatch):
+    """Same inputs through both wave tiles in one process (the knob is read per call): identical bits, ragged tail included."""
+    from landiff_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(7)
+    B, H, N = 2, 3, 3001
+    Npad = (N + 127) // 128 * 128
+    q = torch.zeros(B, H, Npad, 64, device=cuda, dtype=torch.bfloat16); k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, 64, Npad, device=cuda, dtype=torch.bfloat16)
+    q[:, :, :N] = torch.randn(B, H, N, 64, device=cuda, generator=g).to(torch.bfloat16)
+    k[:, :, :N] = torch.randn(B, H, N, 64, device=cuda, generator=g).to(torch.bfloat16)
+    vt[:, :, :, :N] = torch.randn(B, H, 64, N, device=cuda, generator=g).to(torch.bfloat16)
+    outs, names = [], []
+    for knob in ("0", "2"):
+        monkeypatch.setenv("LD_ATTN_Q128", knob)
+        out = torch.zeros(B, N, H * 64, device=cuda, dtype=torch.bfloat16)
+        ops.attn_fwd(q, k, vt, out, N, N, 0.125)
+        outs.append(out); names.append(_last_kernel())
+    assert names == ["ld_attn_q64_kernel", "ld_attn_q128_kernel"], names
+    assert torch.equal(outs[0], outs[1])

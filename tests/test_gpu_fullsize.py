@@ -217,11 +217,17 @@ def test_dit_multi_layer_step_full_shape_vs_oracle(cuda):
         err = (got - r).abs()
         rng, mean = r.abs().max().item(), r.abs().mean().item()
         print(f"3+3-layer step, CFG scale {s_cfg}: max err {err.max().item() / rng:.4f} of the range, mean err {err.mean().item() / mean:.4f} of the mean")
-        # seven bf16 layer-calls deep (single layer: <= 3e-2 / 1e-2 above); the CFG combine amplifies rounding noise by 2 s - 1
-        assert err.max().item() / rng < 4e-2 * amp, (s_cfg, err.max().item(), rng)
-        assert err.mean().item() / mean < 1.5e-2 * amp, (s_cfg, err.mean().item(), mean)
-    # the two rows are different problems (text vs zero text): the device must not have mixed them up
-    assert (outs[0.0] - outs[1.0]).abs().mean().item() > 10 * (outs[1.0] - ref[1.0]).abs().mean().item()
+        # seven bf16 layer-calls deep (measured on MI355X: 0.008 / 0.007 at scale 0 and 1, 0.022 / 0.020 at scale 4: the CFG combine
+        # amplifies rounding noise by up to 2 s - 1); a stride / aliasing fault shows up as O(1)
+        assert err.max().item() / rng < (2e-2 if amp == 1.0 else 6e-2), (s_cfg, err.max().item(), rng)
+        assert err.mean().item() / mean < (1.5e-2 if amp == 1.0 else 5e-2), (s_cfg, err.mean().item(), mean)
+    # the two rows are different problems (zero text vs text) whose outputs differ by LESS than the bf16 noise with random weights
+    # (226 of 17 776 keys): the device's cond - uncond difference must still point the way the oracle's does, i.e. the rows are
+    # not swapped or shared (a swap gives the opposite sign, a shared row zero)
+    dd, dr = (outs[1.0] - outs[0.0]).flatten().double(), (ref[1.0] - ref[0.0]).flatten().double()
+    cos = float(dd @ dr / (dd.norm() * dr.norm() + 1e-30))
+    print(f"cond - uncond: device vs oracle cosine {cos:.3f} (|device| {dd.abs().mean():.5f}, |oracle| {dr.abs().mean():.5f})")
+    assert cos > 0.15, cos
 
 
 def test_tokenizer_encoder_full_size_causality(cuda):

@@ -4,6 +4,10 @@ tests/test_oracle_golden.py (CPU, `-m "not gpu"`) checks the CPU restatement aga
 tests/golden/.  Every GPU parity test compares the HIP path with that oracle, so the `-m gpu` run on the MI355X box would
 otherwise never execute the pin it rests on.  This file runs the same functions again under the gpu marker (they need no GPU
 and take a few seconds): a GPU-tier record is then self-contained -- reference fixtures -> oracle -> HIP path -- on one box.
+
+Cross-host mode: the fixtures were generated in the authoring container; on the GPU box's host CPU torch's vectorised kernels
+round a few table entries one ulp differently (measured: 5 of the 22 cases), so float comparisons run with
+test_oracle_golden.CROSS_HOST = True (rtol 2e-4); token ids, index tables, masks and hashes stay exact.
 """
 import itertools
 
@@ -42,5 +46,6 @@ def test_the_pin_is_complete():
 
 
 @pytest.mark.parametrize("fn,kwargs", CASES)
-def test_oracle_pin(fn, kwargs):
+def test_oracle_pin(fn, kwargs, monkeypatch):
+    monkeypatch.setattr(pin, "CROSS_HOST", True)
     fn(**kwargs)

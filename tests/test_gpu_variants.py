@@ -176,7 +176,11 @@ def test_gemm_main_loop_variants(cuda, env):
 
 @pytest.mark.parametrize("env", [{"LD_ATTN_SAFE": "1"}, {"LD_ATTN_Q64": "0"}, {"LD_ATTN_Q64": "0", "LD_ATTN_SAFE": "1"}, {"LD_ATTN_Q64": "0", "LD_ATTN_NW": "8"}, {"LD_ATTN_Q64": "0", "LD_ATTN_NW": "8", "LD_ATTN_SAFE": "1"}, {"LD_ATTN_VARIANT": "9"}, {"LD_ATTN_VARIANT": "1"}, {"LD_ATTN_VARIANT": "4"},
                                  {"LD_ATTN_VARIANT": "8"}, {"LD_ATTN_VARIANT": "8", "LD_ATTN_SAFE": "1"}, {"LD_ATTN_VARIANT": "8", "LD_ATTN_NW": "8"},
-                                 {"LD_ATTN_Q64": "0", "LD_ATTN_MSUM": "0"}, {"LD_ATTN_Q64": "0", "LD_ATTN_MSUM": "0", "LD_ATTN_SAFE": "1"}])
+                                 {"LD_ATTN_Q64": "0", "LD_ATTN_MSUM": "0"}, {"LD_ATTN_Q64": "0", "LD_ATTN_MSUM": "0", "LD_ATTN_SAFE": "1"},
+                                 # the 128-query-row / one-wave-per-SIMD tile forced onto the small test problems (LD_ATTN_Q128=2), its
+                                 # running-max fallback, and the other two exp2 splits
+                                 {"LD_ATTN_Q128": "2"}, {"LD_ATTN_Q128": "2", "LD_ATTN_SAFE": "1"},
+                                 {"LD_ATTN_Q128": "2", "LD_ATTN_NPRE": "36"}, {"LD_ATTN_Q128": "2", "LD_ATTN_NPRE": "52"}])
 def test_attention_variants(cuda, env):
     assert _run(ATTN_SNIPPET, env) < 2e-2
 
@@ -189,15 +193,18 @@ def test_layernorm_modulate_forms(cuda, env):
 
 
 def test_attention_wave_tiles_bit_identical(cuda):
-    """The 64-query-row wave tile (ld_attn_q64, default) and the 32-row one (LD_ATTN_Q64=0) do the same per-lane arithmetic
-    in the same order -- outputs equal bit for bit, whatever the tail of the key axis looks like."""
+    """The 64-query-row wave tile (ld_attn_q64), the 32-row one (LD_ATTN_Q64=0) and the 128-row one-wave-per-SIMD tile
+    (LD_ATTN_Q128=2: ld_attn_q128.hip, every MFMA / exp2 / pack an asm statement over fixed accumulator registers, three exp2
+    splits) do the same per-lane arithmetic in the same order -- outputs equal bit for bit, whatever the tail of the key axis
+    looks like."""
     outs = []
-    for env in ({}, {"LD_ATTN_Q64": "0"}):
+    for env in ({"LD_ATTN_Q128": "0"}, {"LD_ATTN_Q64": "0", "LD_ATTN_Q128": "0"}, {"LD_ATTN_Q128": "2"},
+                {"LD_ATTN_Q128": "2", "LD_ATTN_NPRE": "36"}, {"LD_ATTN_Q128": "2", "LD_ATTN_NPRE": "52"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", ATTN_HASH_SNIPPET], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
-    assert outs[0] == outs[1]
+    assert all(o == outs[0] for o in outs[1:]), outs
 
 
 def test_groupnorm_apply_forms(cuda):

@@ -22,6 +22,22 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
+# Floating-point tables and trajectories are bit-exact against the fixtures on the host that generated them (this container:
+# the CPU tier, where anyone can regenerate tests/golden/ byte for byte with oracle/gen_golden.py).  torch's vectorised CPU
+# kernels (cumprod, sqrt, exp, sin/cos) round the last bit differently on other micro-architectures -- the MI355X box's
+# EPYC 9575F returns 0.82490206 where the fixture holds 0.8249021 -- and so would the reference itself there.  The GPU-tier
+# re-run of this file (tests/test_gpu_oracle_pin.py) therefore sets CROSS_HOST: float comparisons relax to rtol 2e-4 (measured: 1e-5 on one timestep-embedding entry),
+# integer / boolean / token-id comparisons stay exact.
+CROSS_HOST = False
+
+
+def feq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if not CROSS_HOST:
+        return np.array_equal(a, b)
+    return a.shape == b.shape and bool(np.allclose(a, b, rtol=2e-4, atol=2e-5))      # (50 sampler steps of sin / cos / exp deep)
+
+
 # ---------------------------------------------------------------- schedule / sampler
 def test_schedule_tables_bit_exact():
     from landiff_amd.config import SamplerConfig
@@ -30,16 +46,16 @@ def test_schedule_tables_bit_exact():
     g = load("schedule")
     s = DiffusionSamplerOracle(SamplerConfig())
     a, ts = s.prepare()
-    assert np.array_equal(a.numpy(), g["alpha_cumprod_sqrt"])
+    assert feq(a.numpy(), g["alpha_cumprod_sqrt"])
     assert np.array_equal(ts.numpy(), g["timesteps"])
-    assert np.array_equal(s.denoiser_sigmas.numpy(), g["denoiser_sigmas"])
+    assert feq(s.denoiser_sigmas.numpy(), g["denoiser_sigmas"])
     q, idx = s.quantize_sigma(a[:-1])
-    assert np.array_equal(q.numpy(), g["quantized"]) and np.array_equal(idx.numpy(), g["quantized_idx"])
+    assert feq(q.numpy(), g["quantized"]) and np.array_equal(idx.numpy(), g["quantized_idx"])
     scales = [dynamic_cfg_scale(6, 5, 50, int(50 - t)) for t in ts.tolist()[::-1][:50]]
-    assert np.array_equal(np.array(scales), g["cfg_scales"])
+    assert feq(np.array(scales), g["cfg_scales"])
     assert abs(scales[0] - 2.2915) < 1e-3 and abs(scales[2] - 6.9744) < 1e-3   # SURVEY 3.3 quirk values
     te = timestep_embedding(torch.tensor([999.0, 19.0, 500.0]), 64)
-    assert np.array_equal(te.numpy(), g["timestep_embedding"])
+    assert feq(te.numpy(), g["timestep_embedding"])
 
 
 @pytest.mark.parametrize("name,n,kind", [("vpsde", 50, "vpsde_dpmpp2m"), ("vpsde7", 7, "vpsde_dpmpp2m"), ("ddim", 10, "ddim"),
@@ -59,7 +75,7 @@ def test_sampler_trajectory_bit_exact(name, n, kind):
     cond = torch.randn(1, 5, 8)
     assert np.array_equal(x.numpy(), g[name + "_x0"]) and np.array_equal(cond.numpy(), g[name + "_cond"])
     out = s.run(network, x.clone(), cond, torch.zeros_like(cond), fixed_frames=2 if name == "vpsde_fixed2" else 0)
-    assert np.array_equal(out.numpy(), g[name + "_out"])
+    assert feq(out.numpy(), g[name + "_out"])
     if name == "vpsde_fixed2":
         assert np.array_equal(out[:, :2].numpy(), g[name + "_x0"][:, :2])      # pinned frames come back untouched
 
@@ -71,14 +87,14 @@ def test_rope_tables_and_apply():
     from oracle.tokenizer import rope3d_table
     g = load("rope")
     cos, sin = rope_table(128, 40)
-    assert np.array_equal(cos.numpy(), g["f1_real"]) and np.array_equal(sin.numpy(), g["f1_imag"])
+    assert feq(cos.numpy(), g["f1_real"]) and feq(sin.numpy(), g["f1_imag"])
     q, k = T(g["q"]), T(g["k"])
     np.testing.assert_allclose(apply_rope(q, cos[None], sin[None]).numpy(), g["q_out"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(apply_rope(k, cos[None], sin[None]).numpy(), g["k_out"], rtol=0, atol=1e-6)
     Tn, H, W, nI, nP = g["grid"].tolist()
     cfg = TokenizerConfig(width=128, heads=2, grid_h=H, grid_w=W, temporal=Tn, pframe_tokens=nP, num_latent_tokens=nI + (Tn - 1) * nP)
     c3, s3 = rope3d_table(cfg)
-    assert np.array_equal(c3.numpy(), g["f3_real"]) and np.array_equal(s3.numpy(), g["f3_imag"])
+    assert feq(c3.numpy(), g["f3_real"]) and feq(s3.numpy(), g["f3_imag"])
 
 
 def test_decoder_mask_closed_form():
