@@ -104,7 +104,14 @@ __device__ __forceinline__ uint32_t pack_pinned(float lo, float hi) {
 __device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }    // > the 8-pass MFMA's result latency
 __device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int NPRE>
+// timing experiments only (tools/attn_q128_ablate.sh; results are wrong when any bit is set, the shipped library is built without
+// the macro): 1 no exp2, 2 no packs, 4 no LDS-DMA, 8 no fragment ds_reads, 16 no row-sum MFMAs, 32 no period barrier / waits,
+// 64 no QK^T MFMAs, 128 no PV MFMAs, 256 per-workgroup cycle / real-time counters into kt_min (tools/attn_q128_cycles.py)
+#ifndef LD_Q128_ABLATE
+#define LD_Q128_ABLATE 0
+#endif
+
+template <int NPRE, int SCHED>
 __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_safe, char* smem) {   // smem: K slots 0..3 | V^T slots 0..3 | flag words
   constexpr int NW = Q128_NW, NQB = Q128_NQB;
   constexpr int VBASE = 4 * KTILE_BYTES;
@@ -125,6 +132,9 @@ __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_sa
   const bf16_t* Vb = p.Vt + (long)bh * D * p.Npad;
   const int q0 = qblk * Q128_ROWS + wave * Q128_WROWS;
   if (qblk * Q128_ROWS >= p.Nq) return;
+  // bit 256 (timing builds): shader-clock cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of every workgroup into kt_min
+  unsigned long long t_cyc0 = 0, t_real0 = 0;
+  if (LD_Q128_ABLATE & 256) { t_cyc0 = __builtin_amdgcn_s_memtime(); t_real0 = __builtin_amdgcn_s_memrealtime(); }
 
   // Q^T fragments (B operand): rows q0 + qb*16 + l16, d = ks*32 + h4*8 .. + 8, pre-multiplied by scale * log2(e) -> a[128:191]
   static_for<NQB>([&](auto qc) {
@@ -228,7 +238,7 @@ __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_sa
     acc_write4<AONES>((u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
     f32x4_t sA[2][NQB], sB[2][NQB];
     // the 64 scores of a lane in a half are numbered v = b*32 + qb*4 + r
-    auto EXPV = [&](f32x4_t (&s)[2][NQB], int v) { const int bb = v >> 5, qb = (v >> 2) & 7, r = v & 3; float x = s[bb][qb][r]; exp2_inplace(x); s[bb][qb][r] = x; };
+    auto EXPV = [&](f32x4_t (&s)[2][NQB], int v) { if (LD_Q128_ABLATE & 1) return; const int bb = v >> 5, qb = (v >> 2) & 7, r = v & 3; float x = s[bb][qb][r]; exp2_inplace(x); s[bb][qb][r] = x; };
 
     // One pipelined iteration on half hh (phase PH = hh & 7 fixes every slot).  sc = S_hh (the first NPRE already probabilities),
     // sn receives S_{hh+1}; the K fragments of half hh+2 are fetched and this half's share of the period's DMA pieces issued
@@ -248,12 +258,13 @@ __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_sa
       u32x4_t pw[NQB];                                            // P fragments [qb]
       auto CW = [&](int w) {                                      // packed word w = qb*4 + b*2 + half of the P fragments
         const int qb = w >> 2, bb = (w >> 1) & 1, hf = w & 1;
+        if (LD_Q128_ABLATE & 2) { pw[qb][2 * bb + hf] = __float_as_uint(sc[bb][qb][2 * hf]); return; }
         pw[qb][2 * bb + hf] = pack_pinned(sc[bb][qb][2 * hf], sc[bb][qb][2 * hf + 1]);
       };
       auto DMA = [&](int i) {                 // piece 2 * PER + i of the period's 2 * NPW
         constexpr int g0 = 2 * PER;
         const int g = g0 + i;
-        dma_piece(g % NPW, g < NPW ? dslot0 : dslot1, g < NPW ? dt0 : dt1);
+        if (!(LD_Q128_ABLATE & 4)) dma_piece(g % NPW, g < NPW ? dslot0 : dslot1, g < NPW ? dt0 : dt1);
       };
       // ---- phase 1: QK^T of half hh+1 (32 MFMAs, g = ks*16 + b*8 + qb) over exp2 of scores NPRE..63 of half hh, the packing
       //      of P (one packed word per gap, word qb*4 + b*2 + half in gap of the same number: its scores are finished by then), the
@@ -261,15 +272,19 @@ __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_sa
       lgkm_wait0();                                               // the K fragments requested in the previous phase 2
       static_for<32>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        QK(sn, gc);
+        if constexpr (!(LD_Q128_ABLATE & 64)) QK(sn, gc);
         if constexpr (NPRE + g < 64) EXPV(sc, NPRE + g);
-        CW(g);                                                    // (its two scores were exponentiated >= 3 gaps ago: NPRE >= 36)
+        // packs.  SCHED 0: one word per QK^T gap (its two scores were exponentiated >= 3 gaps ago: NPRE >= 36).  SCHED 1: only
+        // the words of query block 0 here (gaps 27..30: >= 2 instructions before the first PV MFMA reads them), the other blocks'
+        // words under the PV gaps of the block before them -- the QK^T gaps then carry MFMA + exp2 only
+        if constexpr (SCHED == 0) CW(g);
+        else if constexpr (g >= 27 && g < 31) CW(g - 27);
         if constexpr (g == 1) DMA(0);
         if constexpr (g == 5) DMA(1);
-        if constexpr (g == 3) VF(IC<vslot>{}, IC<kg>{}, IC<0>{});
-        if constexpr (g == 7) VF(IC<vslot>{}, IC<kg>{}, IC<1>{});
-        if constexpr (g == 9) VF(IC<vslot>{}, IC<kg>{}, IC<2>{});
-        if constexpr (g == 11) VF(IC<vslot>{}, IC<kg>{}, IC<3>{});
+        if constexpr (g == 3 && !(LD_Q128_ABLATE & 8)) VF(IC<vslot>{}, IC<kg>{}, IC<0>{});
+        if constexpr (g == 7 && !(LD_Q128_ABLATE & 8)) VF(IC<vslot>{}, IC<kg>{}, IC<1>{});
+        if constexpr (g == 9 && !(LD_Q128_ABLATE & 8)) VF(IC<vslot>{}, IC<kg>{}, IC<2>{});
+        if constexpr (g == 11 && !(LD_Q128_ABLATE & 8)) VF(IC<vslot>{}, IC<kg>{}, IC<3>{});
         FENCE();
       });
       if (mask) {
@@ -282,17 +297,18 @@ __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_sa
       static_for<40>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int qb = g / 5, j = g - qb * 5;
-        if constexpr (j < 4) mfma_o<AO(j, qb), AV(j)>(pw[qb]);
-        else mfma_l(lacc[qb], pw[qb]);
+        if constexpr (j < 4) { if constexpr (!(LD_Q128_ABLATE & 128)) mfma_o<AO(j, qb), AV(j)>(pw[qb]); else asm volatile("" :: "v"(pw[qb])); }
+        else if constexpr (!(LD_Q128_ABLATE & 16)) mfma_l(lacc[qb], pw[qb]);
         static_for<(g + 1) * NPRE / 40 - g * NPRE / 40>([&](auto ec) { EXPV(sn, g * NPRE / 40 + decltype(ec)::value); });
-        if constexpr (g == 0) KF(IC<k2slot>{}, IC<kg>{}, IC<0>{});
-        if constexpr (g == 2) KF(IC<k2slot>{}, IC<kg>{}, IC<1>{});
-        if constexpr (g == 4) KF(IC<k2slot>{}, IC<kg>{}, IC<2>{});
-        if constexpr (g == 6) KF(IC<k2slot>{}, IC<kg>{}, IC<3>{});
+        if constexpr (SCHED == 1 && qb < NQB - 1 && j < 4) CW(4 * (qb + 1) + j);      // word j of the NEXT block's P fragment
+        if constexpr (g == 0 && !(LD_Q128_ABLATE & 8)) KF(IC<k2slot>{}, IC<kg>{}, IC<0>{});
+        if constexpr (g == 2 && !(LD_Q128_ABLATE & 8)) KF(IC<k2slot>{}, IC<kg>{}, IC<1>{});
+        if constexpr (g == 4 && !(LD_Q128_ABLATE & 8)) KF(IC<k2slot>{}, IC<kg>{}, IC<2>{});
+        if constexpr (g == 6 && !(LD_Q128_ABLATE & 8)) KF(IC<k2slot>{}, IC<kg>{}, IC<3>{});
         FENCE();
       });
       // ---- end of a period: retire this wave's LDS reads and DMA pieces, then the barrier ----
-      if (PER == 3) {
+      if (PER == 3 && !(LD_Q128_ABLATE & 32)) {
         __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
       }
@@ -382,14 +398,24 @@ __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_sa
           for (int r = 0; r < 4; ++r) o4[r] *= alpha;
           acc_write4<AO(db, qb)>(__builtin_bit_cast(u32x4_t, o4));
         });
+        // exp2, pack, pad, MFMA as pinned statements in THIS order: written as plain expressions, hipcc moved the last pack below
+        // the pad, directly in front of the first PV MFMA, which then read the stale word (no interlock between a VALU write and
+        // an MFMA operand read; the compiler pads it only for instructions it knows to be MFMAs)
         u32x4_t pw;
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
+        for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { s[bb][qb][r] = __builtin_amdgcn_exp2f(s[bb][qb][r] - mn); ls[qb] += s[bb][qb][r]; }
-          pw[2 * bb] = pack_bf16x2(s[bb][qb][0], s[bb][qb][1]);
-          pw[2 * bb + 1] = pack_bf16x2(s[bb][qb][2], s[bb][qb][3]);
+          for (int r = 0; r < 4; ++r) { float x = s[bb][qb][r] - mn; exp2_inplace(x); s[bb][qb][r] = x; }
+        asm volatile("s_nop 1" ::: "memory");                     // v_exp_f32 -> VALU use
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          pw[2 * bb] = pack_pinned(s[bb][qb][0], s[bb][qb][1]);
+          pw[2 * bb + 1] = pack_pinned(s[bb][qb][2], s[bb][qb][3]);
         }
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ls[qb] += s[bb][qb][r];
         asm volatile("s_nop 4" ::: "memory");                     // v_accvgpr_write / v_cvt_pk -> MFMA operand wait states
         static_for<4>([&](auto dc) { mfma_o<AO(decltype(dc)::value, qb), AV(decltype(dc)::value)>(pw); });
         mfma_settle();                                            // (the next block's rescale reads other quads, but keep it simple)
@@ -429,8 +455,13 @@ __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_sa
     for (int w = 0; w < NW; ++w) redo = redo || flags[w] != 0;
     __syncthreads();
   }
-  if (redo) safe_pass();
+  if (redo && !LD_Q128_ABLATE) safe_pass();          // (an ablated fast pass fails its window test: time it, do not redo it)
 
+  if ((LD_Q128_ABLATE & 256) && p.kt_min && tid == 0) {
+    unsigned long long* dbg = (unsigned long long*)p.kt_min + (long)blockIdx.x * 2;
+    dbg[0] = __builtin_amdgcn_s_memtime() - t_cyc0;
+    dbg[1] = __builtin_amdgcn_s_memrealtime() - t_real0;
+  }
   mfma_settle();
   static_for<NQB>([&](auto qc) {
     constexpr int qb = decltype(qc)::value;
@@ -452,15 +483,17 @@ __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_sa
 // The kernel descriptor must cover a[0:227]: the compiler only counts registers it sees, so the entry names the last one.
 // NPRE (scores of the next half exponentiated under the PV phase): 36 is ld_attn_q64.hip's split doubled; larger values move
 // exp2 issues from the QK^T gaps (MFMA + exp2 + pack) into the PV gaps (MFMA + exp2).
-#define LD_Q128_KERNEL(NAME, NPRE_)                                                                       \
+#define LD_Q128_KERNEL(NAME, NPRE_, SCHED_)                                                               \
   __global__ __launch_bounds__(256, 1) void NAME(AttnParams p, int force_safe) {                          \
     extern __shared__ __attribute__((aligned(16))) char smem[];                                           \
     asm volatile("; ld_attn_q128: a[0:227] are owned by the asm statements of this kernel" ::: "a0", "a227"); \
-    attn_q128_body<NPRE_>(p, force_safe, smem);                                                           \
+    attn_q128_body<NPRE_, SCHED_>(p, force_safe, smem);                                                   \
   }
-LD_Q128_KERNEL(ld_attn_q128_kernel, 44)
-LD_Q128_KERNEL(ld_attn_q128_n36_kernel, 36)
-LD_Q128_KERNEL(ld_attn_q128_n52_kernel, 52)
+LD_Q128_KERNEL(ld_attn_q128_kernel, 44, 0)
+LD_Q128_KERNEL(ld_attn_q128_n36_kernel, 36, 0)
+LD_Q128_KERNEL(ld_attn_q128_n52_kernel, 52, 0)
+LD_Q128_KERNEL(ld_attn_q128_s1_kernel, 36, 1)          // packs under the PV phase (LD_ATTN_NPRE=1036)
+LD_Q128_KERNEL(ld_attn_q128_s1n40_kernel, 40, 1)       // (LD_ATTN_NPRE=1040)
 
 }  // namespace
 
@@ -473,14 +506,20 @@ int ld_attn_q128_launch(const AttnParams& p, hipStream_t st) {
   if (safe < 0) { const char* e = getenv("LD_ATTN_SAFE"); safe = e ? atoi(e) : 0; }
   const char* ne = getenv("LD_ATTN_NPRE");            // per call, like LD_ATTN_Q128 (ld_attn.hip)
   const int npre = ne ? atoi(ne) : 44;
-  static thread_local LdSmemCache c44{}, c36{}, c52{};
+  static thread_local LdSmemCache c44{}, c36{}, c52{}, cs1{}, cs2{};
   dim3 grid((unsigned)((long)p.B * p.H * ((p.Npad + Q128_ROWS - 1) / Q128_ROWS)));
-  if (npre == 36 || npre == 52) {
-    auto k = npre == 36 ? ld_attn_q128_n36_kernel : ld_attn_q128_n52_kernel;
-    if (int rc = ld_ensure_dyn_smem((const void*)k, SMEM, npre == 36 ? &c36 : &c52)) return rc;
-    ld_attn_set_last_kernel(npre == 36 ? "ld_attn_q128_n36_kernel" : "ld_attn_q128_n52_kernel");
-    hipLaunchKernelGGL(k, grid, dim3(256), SMEM, st, p, safe);
-    return ld_check_launch("ld_attn_fwd_bf16(q128)");
+  if (npre != 44) {
+    void (*k)(AttnParams, int) = nullptr; LdSmemCache* c = nullptr; const char* name = nullptr;
+    if (npre == 36) { k = ld_attn_q128_n36_kernel; c = &c36; name = "ld_attn_q128_n36_kernel"; }
+    else if (npre == 52) { k = ld_attn_q128_n52_kernel; c = &c52; name = "ld_attn_q128_n52_kernel"; }
+    else if (npre == 1036) { k = ld_attn_q128_s1_kernel; c = &cs1; name = "ld_attn_q128_s1_kernel"; }
+    else if (npre == 1040) { k = ld_attn_q128_s1n40_kernel; c = &cs2; name = "ld_attn_q128_s1n40_kernel"; }
+    if (k) {
+      if (int rc = ld_ensure_dyn_smem((const void*)k, SMEM, c)) return rc;
+      ld_attn_set_last_kernel(name);
+      hipLaunchKernelGGL(k, grid, dim3(256), SMEM, st, p, safe);
+      return ld_check_launch("ld_attn_fwd_bf16(q128)");
+    }
   }
   if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_q128_kernel, SMEM, &c44)) return rc;
   ld_attn_set_last_kernel(safe ? "ld_attn_q128_kernel[safe pass forced]" : "ld_attn_q128_kernel");

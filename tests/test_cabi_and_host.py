@@ -294,4 +294,4 @@ def test_attention_q128_isa_audit():
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         report = mod.audit(mod.build(tmp))
-    assert len(report) == 3 and all("no compiler a[] traffic" in r for r in report)
+    assert len(report) == 5 and all("no compiler a[] traffic" in r for r in report)

@@ -1,11 +1,13 @@
-"""Debug aid for ld_attn_q128: error map of the fast pass and the forced safe pass against torch fp32 (small problems)."""
+"""Debug aid for ld_attn_q128: error map against torch fp32 on the overflow-fallback input (LD_ATTN_SAFE=1: forced safe pass)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from landiff_amd import ops, _lib
-torch.manual_seed(0)
-def run(B, H, N, knob):
+def run(B, H, N, knob, q_scale, spike):
     os.environ["LD_ATTN_Q128"] = knob
-    q = torch.randn(B, H, N, 64).cuda().bfloat16(); k = torch.randn(B, H, N, 64).cuda().bfloat16(); v = torch.randn(B, H, N, 64).cuda().bfloat16()
+    g = torch.Generator().manual_seed(0)
+    q = (torch.randn(B, H, N, 64, generator=g) * q_scale).cuda().bfloat16(); k = torch.randn(B, H, N, 64, generator=g).cuda().bfloat16(); v = torch.randn(B, H, N, 64, generator=g).cuda().bfloat16()
+    if spike:
+        k[:, :, N - 3] = q[:, :, 5] * 4
     Npad = (N + 127) // 128 * 128
     def pack(x):
         o = torch.zeros(B, H, Npad, 64, device="cuda", dtype=x.dtype); o[:, :, :N] = x; return o
@@ -16,16 +18,12 @@ def run(B, H, N, knob):
     ref = (torch.softmax(s, -1) @ v.float()).permute(0, 2, 1, 3).reshape(B, N, H * 64)
     o = out.float()
     nan = torch.isnan(o)
-    err = (o - ref).abs()
-    err[nan] = 9.0
-    print(f"[{name}] N={N}: nan frac {nan.float().mean().item():.4f}, max err {err.max().item():.4f}, mean err {err.mean().item():.5f}")
-    if err.max() > 0.05:
-        rows = (err.max(dim=2).values[0] > 0.05).nonzero().flatten().tolist()
-        cols = (err.max(dim=1).values[0] > 0.05).nonzero().flatten().tolist()
-        print("  bad rows:", len(rows), rows[:40], "...", rows[-8:])
-        print("  bad cols:", len(cols), cols[:70])
-        r0 = rows[0]
-        print("  row", r0, "got", o[0, r0, :8].tolist(), "ref", ref[0, r0, :8].tolist())
-for N in (1152, 2048, 1122):
-    run(1, 1, N, "0")
-    run(1, 1, N, "2")
+    err = (o - ref).abs(); err[nan] = 9.0
+    print(f"[{name}] N={N} q_scale={q_scale} spike={spike}: nan frac {nan.float().mean().item():.4f}, max err {err.max().item():.4f} (ref absmax {ref.abs().max().item():.2f})")
+    if nan.any():
+        rows = nan.any(dim=2)[0].nonzero().flatten().tolist()
+        cols = nan.any(dim=1)[0].nonzero().flatten().tolist()
+        print("  nan rows:", len(rows), rows[:24], "...", rows[-6:], " nan cols:", len(cols), cols[:12])
+for qs, sp in ((6.0, True), (6.0, False), (1.0, True)):
+    run(1, 2, 1122, "0", qs, sp)
+    run(1, 2, 1122, "2", qs, sp)
