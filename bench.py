@@ -22,13 +22,148 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 METRIC = "end-to-end frames/sec, 49f 480x720 @50 steps"
-# HBM bytes per attention launch at the headline shape from separate rocprofv3 --pmc passes
-# (profiles/r02_attn_q64_pmc_hbm.txt): (2 x FETCH_SIZE [gfx950 correction, MI355X_MICROARCH.md HBM] + WRITE_SIZE) x 1024
-# = (2 * 489400 + 141700) KiB.  Reported only when the run is that kernel at that shape.
-ATTN_TRAFFIC = {"kernel": "ld_attn_q64_kernel", "bytes": (2 * 489400 + 141700) * 1024}
+# HBM bytes per attention launch at the headline shape: read from the newest profiles/r*_attn_pmc_hbm.txt, the summary of separate
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over tools/attn_one.py (tools/pmc_attn.sh writes it, with the gfx950
+# FETCH_SIZE correction of MI355X_MICROARCH.md applied).  Reported only when the run is that kernel at that shape.
+def _attn_traffic():
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_attn_pmc_hbm.txt")))
+    for f in reversed(files):
+        m = re.search(r"^TRAFFIC_BYTES (\d+) KERNEL (\S+)", open(f).read(), re.M)
+        if m:
+            return {"kernel": m.group(2), "bytes": int(m.group(1)), "source": os.path.relpath(f, ROOT)}
+    return {"kernel": None, "bytes": None, "source": None}
+
+
+ATTN_TRAFFIC = _attn_traffic()
 MFMA_BF16_PEAK = 2500.0      # TFLOP/s, dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK = 8000.0            # GB/s
 VAE_TFLOP = 315.0            # per 49-frame video (58.8 + 5 x 51.3)
+
+
+class ClockPowerSampler:
+    """sclk / socket power of the GPU this rank runs on, sampled from sysfs hwmon files (freq1_input, power1_input) by a helper
+    thread that never touches HIP.  The card is found by the PCI address of the torch device; None when the files are not there."""
+
+    def __init__(self, dev, period=0.2):
+        import glob
+        self.period, self.samples, self._run, self._thread = period, [], False, None
+        self.freq = self.power = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            want = None
+        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            hw = glob.glob(os.path.join(card, "hwmon", "hwmon*"))
+            if not hw or not os.path.exists(os.path.join(hw[0], "freq1_input")):
+                continue
+            if want is None or os.path.basename(os.path.realpath(card)) == want:
+                self.freq, self.power = os.path.join(hw[0], "freq1_input"), os.path.join(hw[0], "power1_input")
+                self.card = os.path.basename(os.path.realpath(card))
+                break
+
+    def _loop(self):
+        while self._run:
+            try:
+                f = int(open(self.freq).read()) / 1e6
+                w = int(open(self.power).read()) / 1e6 if os.path.exists(self.power) else float("nan")
+                self.samples.append((f, w))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def start(self):
+        if self.freq is None:
+            return
+        import threading
+        self.samples, self._run = [], True
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._run = False
+        self._thread.join()
+        if not self.samples:
+            return None
+        f = [a for a, _ in self.samples]; w = [b for _, b in self.samples if b == b]
+        return {"mean_sclk_mhz": round(sum(f) / len(f), 0), "min_sclk_mhz": round(min(f), 0), "max_sclk_mhz": round(max(f), 0),
+                "mean_power_w": round(sum(w) / len(w), 0) if w else None, "samples": len(f), "pci": self.card}
+
+
+def calibrate(dev, sampler):
+    """What THIS box sustains, measured right before the timed region (~1 s each): an MFMA-only loop on random bf16 operands
+    (ld_calib_mfma_bf16: no memory traffic, the matrix pipe under the chip's power governor) and a 16-byte-per-lane streaming read
+    of 1 GiB (ld_calib_stream_read).  The roofline fractions against the datasheet peaks stay the headline; `frac_of_box_ceiling`
+    divides by these instead, which takes the +-4-5 % box-to-box spread of the pool out of a round-over-round comparison."""
+    import ctypes
+    from landiff_amd import _lib
+    from landiff_amd._lib import check
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ops_ = torch.randn(1 << 19, device=dev).to(torch.bfloat16)                    # 1 MiB of random operands
+    sink = torch.zeros(4, device=dev, dtype=torch.float32)
+    isink = torch.zeros(4, device=dev, dtype=torch.int32)
+    buf = torch.empty(1 << 28, device=dev, dtype=torch.int32).random_()          # 1 GiB: four times the Infinity Cache
+    flops = ctypes.c_double(0.0)
+    res = {}
+
+    def timed(launch, seconds):
+        launch(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0, n = time.perf_counter(), 0
+        e0.record()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(4):
+                launch()
+            n += 4
+            torch.cuda.synchronize()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / n
+
+    sampler.start()
+    dt = timed(lambda: check(lib.ld_calib_mfma_bf16(ctypes.c_void_p(ops_.data_ptr()), ops_.numel() * 2, ctypes.c_void_p(sink.data_ptr()),
+                                                    2048, 2000, ctypes.byref(flops), st), "ld_calib_mfma_bf16"), 1.0)
+    clk = sampler.stop()
+    res["mfma_tflops"] = round(flops.value / dt / 1e12, 1)
+    res["mfma_loop_sclk_mhz"] = clk["mean_sclk_mhz"] if clk else None
+    dt = timed(lambda: check(lib.ld_calib_stream_read(ctypes.c_void_p(buf.data_ptr()), buf.numel() * 4, ctypes.c_void_p(isink.data_ptr()), st),
+                             "ld_calib_stream_read"), 1.0)
+    res["hbm_gbs"] = round(buf.numel() * 4 / dt / 1e9, 1)
+    res["what"] = ("1 s each before the timed region: MFMA-only loop (v_mfma_f32_16x16x32_bf16, random operands, one wave per SIMD) "
+                   "and a 16-B/lane read of 1 GiB; sclk / power: sysfs hwmon of this GPU sampled every 0.2 s")
+    del buf
+    torch.cuda.empty_cache()
+    return res
+
+
+def detok_tflop(cfg) -> float:
+    """Algorithmic FLOPs of the detokenize stage (TiTok decoder: linears + frame-masked attention at its 0.5385 mask density;
+    conv upsampler + conv_out), in TFLOP."""
+    from landiff_amd.weights import upsampler_levels
+    t, u = cfg.tok, cfg.ups
+    N, w = t.seq_len, t.width
+    lin = t.layers * 2.0 * N * (3 * w * w + w * w + 8 * w * w)
+    fid_density = 0.5385 if t.temporal == 13 else 0.6
+    attn = t.layers * 4.0 * t.heads * N * N * t.head_dim * fid_density
+    head = 2.0 * t.n_visual * (w * 2 * w + 2 * w * t.out_channels) if hasattr(t, "n_visual") else 0.0
+    F, H, W = t.temporal, t.grid_h, t.grid_w
+    conv = lambda cin, cout, h, ww: 2.0 * F * h * ww * cin * cout * 9
+    top = u.ch * u.ch_mult[-1]
+    fl = conv(u.z_channels, top, H, W) + 4 * conv(top, top, H, W)
+    ch = top
+    for lvl, blocks, up in upsampler_levels(u):
+        for cin, cout in blocks:
+            fl += conv(cin, cout, H, W) + conv(cout, cout, H, W) + (2.0 * F * H * W * cin * cout if cin != cout else 0.0)
+            ch = cout
+        if up:                      # PixelShuffle(2), then Conv2d(C / 4 -> C) at twice the resolution
+            H, W = 2 * H, 2 * W
+            fl += conv(ch // 4, ch, H, W)
+    fl += conv(ch, u.out_ch, H, W) + conv(u.out_ch, u.target_dim, H, W)
+    return (lin + attn + head + fl) / 1e12
 
 
 def _median(fn, n=5):
@@ -204,17 +339,21 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    sampler = ClockPowerSampler(dev)
+    calib = calibrate(dev, sampler) if rank == 0 else None
     pipe.timings = {}
-    pipe.dit.attn_events = []
-    pipe.dit.gemm_events = []
+    pipe.dit.attn_events = []                 # HIP events around every attention launch: the roofline object's `achieved`
+    pipe.dit.gemm_events = None               # (the GEMM events are collected in a separate, untimed step below)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step()
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0
+    clocks = sampler.stop()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -225,6 +364,16 @@ def main():
 
     n_frames = out[0].shape[1]
     stage_s = {k: v / args.steps for k, v in pipe.timings.items()}
+    gemm_step_s = None
+    if rank == 0 and not args.fp8_gemm and not stream and P == 1:
+        # one more step OUTSIDE the timed region with HIP events around every large DiT Linear (~20 k event records per video
+        # would otherwise sit in the headline number)
+        keep_t, keep_a = pipe.timings, pipe.dit.attn_events
+        pipe.timings, pipe.dit.attn_events, pipe.dit.gemm_events = {}, None, []
+        one_step()
+        torch.cuda.synchronize()
+        gemm_step_s = dict(pipe.timings)
+        pipe.timings, pipe.dit.attn_events = keep_t, keep_a
     reports = gather_rank_reports({"rank": rank, "frames_per_s": round(n_frames * args.steps / local_elapsed, 4),
                                    "stage_seconds": {k: round(v, 3) for k, v in stage_s.items()},
                                    "cores": len(my_cores) if my_cores else None}, world if use_dist else 1)
@@ -243,7 +392,8 @@ def main():
         attn_roof = {"kernel": "%s (DiT joint text+video attention, B=2,H=%d,N=%d,D=64)" % (kname, d.heads, d.seq_len),
                      "bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4),
-                     "traffic": ATTN_TRAFFIC["bytes"] if headline else None, "launches": len(ev),
+                     "traffic": ATTN_TRAFFIC["bytes"] if headline else None, "traffic_source": ATTN_TRAFFIC["source"] if headline else None,
+                     "launches": len(ev),
                      "avg_launch_ms": round(attn_ms, 4)}
         # ---- per-stage achieved vs peak (rank 0) ----------------------------------------------------
         stages = {"dit_attention": {k: attn_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
@@ -254,9 +404,16 @@ def main():
             g_fl = sum(f for _, _, f in gev)
             g_ach = g_fl / g_s / 1e12
             stages["dit_gemm"] = {"bound": "mfma", "achieved": round(g_ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(g_ach / peak, 4),
-                                  "seconds_per_step": round(g_s / args.steps, 3), "launches": len(gev),
+                                  "seconds_per_step": round(g_s, 3), "launches": len(gev),
                                   "what": "HIP events around every qkv / dense / 4h / 4h->h Linear and control zero-linear of the DiT loop "
-                                          "(2 M N K each; 3.145 TFLOP per layer-call + 0.262 per control layer), tail launches included"}
+                                          "(2 M N K each; 3.145 TFLOP per layer-call + 0.262 per control layer), tail launches included; "
+                                          "collected in ONE extra step after the timed region (the headline loop carries no GEMM events)"}
+        if "detokenize" in stage_s and not stream and P == 1 and not args.tiny:
+            dtf = detok_tflop(cfg)
+            stages["detokenize"] = {"bound": "mfma", "achieved": round(dtf / stage_s["detokenize"], 1), "peak": peak, "unit": "TFLOP/s",
+                                    "frac": round(dtf / stage_s["detokenize"] / peak, 4), "seconds_per_step": round(stage_s["detokenize"], 4),
+                                    "what": "%.2f TFLOP (TiTok decoder linears + frame-masked attention at its mask density, conv upsampler, conv_out) "
+                                            "/ the detokenize stage's wall time" % dtf}
         if "llm" in stage_s and not stream and P == 1 and not args.tiny:
             steps_llm = 1244
             gbs = llm_step_bytes(cfg.llm) * steps_llm / stage_s["llm"] / 1e9
@@ -292,7 +449,20 @@ def main():
                        "parallelism": f"dp{world} over prompts, RCCL all_gather of uint8 frames only"},
             "roofline": attn_roof,
             "roofline_stages": stages,
+            "stage_figures_note": "llm_decode / vae_decode / detokenize divide the stage's algorithmic bytes or FLOPs by its WALL time "
+                                  "(prefill, norm, upsample, uint8 passes and launch gaps included); dit_attention / dit_gemm are HIP-event "
+                                  "kernel times",
+            "calibration": dict(calib or {}, **({"timed_region": clocks} if clocks else {})),
         }
+        if calib:                # the same fractions against what THIS box sustained a few seconds earlier
+            boxc = {"dit_attention": round(achieved / calib["mfma_tflops"], 4)}
+            if "dit_gemm" in stages:
+                boxc["dit_gemm"] = round(stages["dit_gemm"]["achieved"] / calib["mfma_tflops"], 4)
+            if "vae_decode" in stages:
+                boxc["vae_decode"] = round(stages["vae_decode"]["achieved"] / calib["mfma_tflops"], 4)
+            if "llm_decode" in stages:
+                boxc["llm_decode"] = round(stages["llm_decode"]["achieved"] / calib["hbm_gbs"], 4)
+            res["frac_of_box_ceiling"] = boxc
         if not serving:            # generate_many records no per-stage wall times (its stages overlap)
             res["stage_seconds_rank0"] = {k: round(v, 3) for k, v in stage_s.items()}
         if world > 1 or use_dist:

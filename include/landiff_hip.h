@@ -21,7 +21,7 @@ extern "C" {
 /* Bumped whenever a signature changes or an entry point is added / removed (2: ld_groupnorm_stats took its `partials`
  * argument, ld_gemm_qkv_heads / ld_llm_sample_advance / ld_groupnorm_stats_blocks / ld_attn_last_kernel were added).  A caller
  * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does). */
-#define LD_ABI_VERSION 4
+#define LD_ABI_VERSION 5
 
 int ld_version(void);
 const char* ld_last_error(void);
@@ -91,6 +91,14 @@ int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int64_t ld
  * over the padded input: inputs below 2 GiB only -- larger ones are routed to 1), negative = the shape is refused
  * (e.g. a padded input of 8 GiB or more).  Host logic only; lets the size guard be tested on CPU. */
 int ld_conv_route(int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t kT, int64_t kH, int64_t kW);
+
+/* ---- calibration loops for bench.py (not on the product path; ld_calib.hip) ----
+ * ld_calib_mfma_bf16: n_workgroups x 256 threads (one wave per SIMD), `iters` trips of 128 v_mfma_f32_16x16x32_bf16 per wave on
+ * operands taken once from `operands` (random bf16: the matrix pipe's power depends on the operand bits); *flops_out = FLOP of
+ * the launch.  ld_calib_stream_read: one pass of 16-byte non-temporal loads over `bytes`. */
+int ld_calib_mfma_bf16(const void* operands, int64_t operand_bytes, float* sink, int64_t n_workgroups, int64_t iters,
+                       double* flops_out, void* stream);
+int ld_calib_stream_read(const void* buf, int64_t bytes, uint32_t* sink, void* stream);
 
 /* ---- optional fp8 (OCP e4m3) form of the DiT's large linear layers (BASELINE.json configs[4]; the headline metric and
  * every parity claim of the bf16 path stay on ld_gemm_bf16) ---- */

@@ -44,7 +44,7 @@ class LlmLayer(Structure):
 
 
 _lib = None
-ABI_VERSION = 4          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
+ABI_VERSION = 5          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
 
 I64 = c_int64
 I32 = c_int32
@@ -58,6 +58,8 @@ SIGNATURES: dict[str, list] = {
     "ld_gemm_qkv_heads": [P, I64, P, P, I64, I64, P, P, P, I64, I64, I64, I64, P, P, P, P, c_float, P],
     "ld_conv_cl_bf16": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, POINTER(Epilogue), P],
     "ld_conv_route": [I64, I64, I64, I64, I64, I64, I64, I64],
+    "ld_calib_mfma_bf16": [P, I64, P, I64, I64, POINTER(c_double), P],
+    "ld_calib_stream_read": [P, I64, P, P],
     "ld_attn_fwd_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_float, P, P, P, P, P],
     "ld_attn_last_kernel": [],
     "ld_gemv": [P, I64, I32, P, P, I32, P, P, I64, P, I64, I32, I64, I64, I64, I32, I32, P, c_float, P],

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/landiff_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.ld_version() == _lib.ABI_VERSION == 4
+    assert lib.ld_version() == _lib.ABI_VERSION == 5
     assert ctypes.sizeof(_lib.Epilogue) == 120          # layout of ld_epilogue_t
 
 
