@@ -1005,6 +1005,211 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Software-pipelined main loop (round 4; LD_GEMM_SP=1): the 256 x 256 x 64 tile / 8 waves (2 x 4, 128 x 64 per wave) /
+// 16x16x32 MFMAs of ld_gemm8p_kernel, but every wave pipelines ITS OWN fragment reads under its own MFMAs and the workgroup
+// meets ONCE per K-tile instead of eight times:
+//   * a K-tile = 4 stages of 16 MFMAs (k-step ks x row half of the wave tile); while a stage's MFMAs issue, the wave's
+//     ds_read_b128 for the NEXT stage go out in between them into a second fragment register set (two A sets + two W sets of
+//     4 fragments = 64 registers next to the 128 accumulators);
+//       S0 (ks 0, rows 0-63):   reads A rows 64-127 ks 0
+//       S1 (ks 0, rows 64-127): reads A rows 0-63 ks 1 and W ks 1
+//       S2 (ks 1, rows 0-63):   reads A rows 64-127 ks 1               -- the wave's last reads of this K-tile
+//       [lgkmcnt(0), vmcnt(0): K-tile t+1 has landed; s_barrier: every wave is done reading K-tile t]
+//       S3 (ks 1, rows 64-127): issues the 8 LDS-DMA pieces of K-tile t+2 into the buffer just freed and reads A rows 0-63 / W
+//                               ks 0 of K-tile t+1 from the other buffer
+//   * LDS: two K-tile buffers of 64 KB (A tile 256 rows x 128 B | W tile 256 rows x 128 B, chunk index XOR ((row >> 1) & 7) on
+//     the DMA source and on the read); a wave stages pieces 4 w .. 4 w + 3 (8 rows each) of both tiles: one per-lane byte
+//     offset per piece parity, the rest of the address in the SGPR offset.
+//   * persistent tiles, epilogues and the next tile's first K-tile requested from inside the epilogue: as ld_gemm8p_kernel.
+// The matrix pipe no longer waits for a partner wave to get through a load segment and seven of the eight barriers per K-tile
+// are gone; what a DMA has to land in is one K-tile (~2300 cycles) instead of 1.5-2.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void ld_gemm_sp_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256;
+  constexpr int TILE = 256 * 128, KBUF = 2 * TILE;        // A tile | W tile per K-tile buffer
+  constexpr int EPI_BYTES = (EPI == EPI_QKV) ? 8 * QKV_REGION : 8 * 32 * CW_STRIDE * 4;
+  constexpr int EPI_OFF = (LD_LDS_TOTAL - EPI_BYTES) & ~15;
+  constexpr bool PREFETCH = EPI_OFF >= KBUF;
+  constexpr bool SWAPACC = EPI != EPI_QKV;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int ntiles = nbm * nbn;
+  const int gm_sz = p.group_m;
+  auto tile_origin = [&](int v, int& m0, int& n0) {
+    const int bid = xcd_remap(v, ntiles);
+    const int per_group = gm_sz * nbn;
+    const int group = bid / per_group, in_group = bid - group * per_group;
+    const int first_m = group * gm_sz;
+    const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+    m0 = p.m_begin + (first_m + in_group % rows_here) * BM;
+    n0 = (in_group / rows_here) * BN;
+  };
+  const auto clip = [](long v) { return (int)(v < 0x7fffffffL ? v : 0x7fffffffL); };
+  struct Src { const bf16_t* a; const bf16_t* w; int a_bytes, w_bytes; };
+  auto tile_src = [&](int m0, int n0) {
+    Src s;
+    s.a = p.A + (long)m0 * p.lda;
+    s.w = p.W + (long)n0 * p.K;
+    s.a_bytes = clip(((long)(p.M - m0) * p.lda) * 2);
+    s.w_bytes = clip(((long)(p.N - n0) * p.K) * 2);
+    return s;
+  };
+  // staging: piece 4 * wave + i (i = 0..3) of each tile = local rows 32 * wave + 8 * i + (lane >> 3); the swizzle key
+  // ((row >> 1) & 7) = (4 * i + (lane >> 4)) & 7 depends on the parity of i only, the 16-row step of i >> 1 goes into the SGPR offset
+  uint32_t offA[2], offW[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int lr = wave * 32 + par * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+    offA[par] = (uint32_t)(((long)lr * p.lda + chunk * 8) * 2);
+    offW[par] = (uint32_t)(((long)lr * p.K + chunk * 8) * 2);
+  }
+  const int stepA = (int)(16 * p.lda * 2), stepW = 16 * p.K * 2;       // bytes per 16 rows
+  const int nk = p.K / BK;
+  char* const my_piece = smem + wave * 4096;
+  auto stage_piece = [&](const Src& s, auto bufc, auto ic, int kt, bool weights) {
+    constexpr int B = decltype(bufc)::value, i = decltype(ic)::value;
+    constexpr int OFF = B * KBUF + i * 1024;
+    if (!weights) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)s.a, 0, s.a_bytes, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(my_piece + OFF), 16, offA[i & 1],
+                                               kt * (BK * 2) + (i >> 1) * stepA, 0, 0);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)s.w, 0, s.w_bytes, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(my_piece + TILE + OFF), 16, offW[i & 1],
+                                               kt * (BK * 2) + (i >> 1) * stepW, 0, 0);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  auto stage_ktile = [&](const Src& s, auto bufc, int kt) {
+    stage_piece(s, bufc, I0{}, kt, false); stage_piece(s, bufc, I0{}, kt, true);
+    stage_piece(s, bufc, I1{}, kt, false); stage_piece(s, bufc, I1{}, kt, true);
+    stage_piece(s, bufc, I2{}, kt, false); stage_piece(s, bufc, I2{}, kt, true);
+    stage_piece(s, bufc, I3{}, kt, false); stage_piece(s, bufc, I3{}, kt, true);
+  };
+  // fragment reads
+  int rdA[2], rdW[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c = (ks * 4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7);
+    rdA[ks] = (wr * 128 + (lane & 15)) * 128 + (c << 4);
+    rdW[ks] = TILE + (wc * 64 + (lane & 15)) * 128 + (c << 4);
+  }
+  f32x4_t acc[8][4];
+  bf16x8_t aP[4], aR[4], wQ[4], wS[4];
+  auto ld_a = [&](bf16x8_t& d, auto bufc, int ks, int blk) { d = *(const bf16x8_t*)(smem + rdA[ks] + decltype(bufc)::value * KBUF + blk * 2048); };
+  auto ld_w = [&](bf16x8_t& d, auto bufc, int ks, int blk) { d = *(const bf16x8_t*)(smem + rdW[ks] + decltype(bufc)::value * KBUF + blk * 2048); };
+  bool wave_live = true;
+  auto mm = [&](int ib, int j, const bf16x8_t& a, const bf16x8_t& w) {
+    acc[ib][j] = SWAPACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc[ib][j], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc[ib][j], 0, 0, 0);
+  };
+#define SPF() __builtin_amdgcn_sched_barrier(0)
+  // one stage: 16 MFMAs on (a[0..3] -> row blocks r0 .. r0 + 3) x (w[0..3]); `side(g)` issues the stage's loads / DMA in gap g
+  // (LIVE = false: a wave whose 64 columns lie past N takes part in the staging and the barriers but issues no MFMAs)
+  auto stage16 = [&](auto livec, int r0, const bf16x8_t (&a)[4], const bf16x8_t (&w)[4], auto&& side) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      if constexpr (decltype(livec)::value) mm(r0 + (g >> 2), g & 3, a[g >> 2], w[g & 3]);
+      side(g);
+      SPF();
+    }
+  };
+  // stage2c / morec (compile time): K-tile kt + 2 / kt + 1 exists -- the steady-state loop carries no tests
+  auto ktile = [&](auto bufc, const Src& src, int kt, auto livec, auto stage2c, auto morec) {
+    constexpr int B = decltype(bufc)::value;
+    using Bc = std::integral_constant<int, B>;
+    using Nc = std::integral_constant<int, B ^ 1>;
+    stage16(livec, 0, aP, wQ, [&](int g) { if ((g & 3) == 1) ld_a(aR[g >> 2], Bc{}, 0, 4 + (g >> 2)); });
+    stage16(livec, 4, aR, wQ, [&](int g) {
+      if ((g & 3) == 0) ld_a(aP[g >> 2], Bc{}, 1, g >> 2);
+      if ((g & 3) == 2) ld_w(wS[g >> 2], Bc{}, 1, g >> 2);
+    });
+    stage16(livec, 0, aP, wS, [&](int g) { if ((g & 3) == 1) ld_a(aR[g >> 2], Bc{}, 1, 4 + (g >> 2)); });
+    __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): this wave's last reads of K-tile kt are in registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // its pieces of K-tile kt + 1 have landed
+    SPF(); __builtin_amdgcn_s_barrier(); SPF();
+    constexpr bool more = decltype(morec)::value, stage2 = decltype(stage2c)::value;
+    stage16(livec, 4, aR, wS, [&](int g) {
+      if constexpr (stage2) {
+        if (g == 0) stage_piece(src, Bc{}, I0{}, kt + 2, false);
+        if (g == 2) stage_piece(src, Bc{}, I0{}, kt + 2, true);
+        if (g == 4) stage_piece(src, Bc{}, I1{}, kt + 2, false);
+        if (g == 6) stage_piece(src, Bc{}, I1{}, kt + 2, true);
+        if (g == 8) stage_piece(src, Bc{}, I2{}, kt + 2, false);
+        if (g == 10) stage_piece(src, Bc{}, I2{}, kt + 2, true);
+        if (g == 12) stage_piece(src, Bc{}, I3{}, kt + 2, false);
+        if (g == 14) stage_piece(src, Bc{}, I3{}, kt + 2, true);
+      }
+      if constexpr (more) {
+        if ((g & 3) == 1) ld_a(aP[g >> 2], Nc{}, 0, g >> 2);
+        if ((g & 3) == 3) ld_w(wQ[g >> 2], Nc{}, 0, g >> 2);
+      }
+    });
+  };
+
+  bool k0_staged = false;
+  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+    int m0, n0;
+    tile_origin(v, m0, n0);
+    const Src src = tile_src(m0, n0);
+    wave_live = n0 + wc * 64 < p.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // ---- prologue: K-tile 0 landed, K-tile 1 in flight; first fragments in registers ----
+    if (!k0_staged) stage_ktile(src, I0{}, 0);
+    if (nk > 1) {
+      stage_ktile(src, I1{}, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    SPF(); __builtin_amdgcn_s_barrier(); SPF();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { ld_a(aP[b], I0{}, 0, b); ld_w(wQ[b], I0{}, 0, b); }
+    using T = std::true_type; using F = std::false_type;
+    auto kloop = [&](auto livec) {                                  // nk is even and >= 4 (launcher)
+      int kt = 0;
+      for (; kt + 2 < nk; kt += 2) {
+        ktile(I0{}, src, kt, livec, T{}, T{});
+        ktile(I1{}, src, kt + 1, livec, T{}, T{});
+      }
+      ktile(I0{}, src, kt, livec, F{}, T{});
+      ktile(I1{}, src, kt + 1, livec, F{}, F{});
+    };
+    if (wave_live) kloop(T{}); else kloop(F{});
+    // (every LDS read of this tile completed before its last barrier: the epilogue may overwrite the buffers)
+    const int vn = v + gridDim.x;
+    bool hooked = false;
+    Src nsrc = src;
+    k0_staged = false;
+    if (PREFETCH && vn < ntiles) {
+      int m1, n1;
+      tile_origin(vn, m1, n1);
+      nsrc = tile_src(m1, n1);
+      k0_staged = true;
+    }
+    auto hook = [&]() {
+      if (!hooked && k0_staged) stage_ktile(nsrc, I0{}, 0);
+      hooked = true;
+    };
+    if constexpr (EPI == EPI_QKV) qkv_epilogue16<4>(p, acc, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
+    else gemm_epilogue16<4, EPI, 4, SWAPACC>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
+    hook();
+    if (vn < ntiles) __syncthreads();
+  }
+#undef SPF
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) x fp8 -> fp32 GEMM for the DiT's four large linear layers (BASELINE config 5; never the headline
 // metric, which is bf16).  Same 256x256 tile / 8 waves (2 x 4, 128x64 per wave) / two-stage LDS-DMA structure as
 // ld_gemm_kernel: a K-tile is again 128 BYTES per row -- now 128 elements -- so the DMA pieces, the XOR swizzle and the
@@ -1402,6 +1607,17 @@ int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
   }
   dim3 grid((unsigned)((persist && ntiles > ncu) ? ncu : ntiles)), block(512);
   const int epi = pick_epilogue(p);
+  // LD_GEMM_SP=1 (read per call: tools/gemm_ab.py times both loops alternately in one process): the software-pipelined loop
+  const char* spe = getenv("LD_GEMM_SP");
+  if (!conv && spe && atoi(spe) == 1 && (p.K / BK) % 2 == 0 && p.K / BK >= 4) {
+    switch (epi) {
+      case EPI_QKV: return launch_kernel<ld_gemm_sp_kernel<EPI_QKV>>("ld_gemm_qkv_heads(sp)", grid, block, SMEM, stream, p);
+      case EPI_BIAS: return launch_kernel<ld_gemm_sp_kernel<EPI_BIAS>>("ld_gemm_sp", grid, block, SMEM, stream, p);
+      case EPI_GELU: return launch_kernel<ld_gemm_sp_kernel<EPI_GELU>>("ld_gemm_sp", grid, block, SMEM, stream, p);
+      case EPI_GATE: return launch_kernel<ld_gemm_sp_kernel<EPI_GATE>>("ld_gemm_sp", grid, block, SMEM, stream, p);
+      default: return launch_kernel<ld_gemm_sp_kernel<EPI_GENERIC>>("ld_gemm_sp", grid, block, SMEM, stream, p);
+    }
+  }
   if (epi == EPI_QKV) {
     LD_REQUIRE(!conv, "ld_gemm_qkv_heads: not a convolution epilogue");
     return launch_kernel<ld_gemm8p_kernel<false, EPI_QKV>>("ld_gemm_qkv_heads", grid, block, SMEM, stream, p);
