@@ -371,17 +371,25 @@ class LLMRunner:
                 note_position(S_last + 2 + it)
                 if logits_log is not None:
                     logits_log.append(self.cfg_logits.clone())
+                if self._mode != "chain" and (it & 63) == 63:
+                    self._raise_on_wait_timeout()          # opt-in forms only: one host sync per 64 steps instead of ~1244 steps on garbage
         finally:
             self._pos_host = -1            # any other caller of _decode_forward gets the device-side position
         self.host_enqueue_s = time.perf_counter() - t_enq      # host time to enqueue the loop (< wall time when the GPU is the bound)
-        if (self._mode == "fused" and int(self.fused_ctl[1].item()) != 0) or (self._mode == "chained" and int(self.chain_ctl[0].item()) != 0):
-            raise RuntimeError(f"LLM decode ({self._mode}): a device-side wait timed out (the decode did not have the GPU to itself?); "
-                               "rerun with mode='chain' / LD_LLM_DECODE=chain")
+        self._raise_on_wait_timeout()
         assert int(self.out_count.item()) == n_visual, (int(self.out_count.item()), n_visual)
         out = self.out_tokens[:n_visual]
         if first_frame_tokens is not None:
             out = torch.cat([first_frame_tokens.reshape(-1).to(dev, torch.int64), out])
         return out.clamp(0, c.visual_vocab - 1)
+
+    def _raise_on_wait_timeout(self):
+        """The 'fused' and 'chained' forms spin-wait on other workgroups without a cooperative launch; a wait that gives up sets a
+        device flag.  After that the barrier counters are out of step and the KV cache holds rows computed from stale inputs: the
+        runner must not be used for another decode step before the next sample() (which re-zeroes the control words and prefills)."""
+        if (self._mode == "fused" and int(self.fused_ctl[1].item()) != 0) or (self._mode == "chained" and int(self.chain_ctl[0].item()) != 0):
+            raise RuntimeError(f"LLM decode ({self._mode}): a device-side wait timed out (the decode did not have the GPU to itself?); "
+                               "the KV cache of this decode is invalid; rerun with mode='chain' / LD_LLM_DECODE=chain")
 
     def _capture(self, guided, scale, temperature, generator):
         """Capture one decode step (forward + sampling + advance) into a HIP graph."""

@@ -372,6 +372,10 @@ def pin_rank_cores(local_rank: int, local_world: int) -> list:
     if mine:
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, min(len(mine), torch.get_num_threads())))
+        if local_world > 1 and len(mine) < 2:
+            import warnings
+            warnings.warn(f"rank {local_rank}: {len(mine)} host core(s) per rank -- the AR decode's enqueue loop (~0.5 ms of host time per "
+                          "1.2 ms step) shares its core with the process's other threads; expect a lower decode rate")
     return mine
 
 

@@ -59,6 +59,31 @@ def test_dit_denoise_step(cuda, setup):
     assert rel(out, den_c) < 2e-2, rel(out, den_c)
 
 
+def test_dit_step_with_overlapped_control_branch_is_bit_identical(cuda, setup, monkeypatch):
+    """LD_DIT_OVERLAP=1: the control branch on a second stream, one layer ahead of the main branch (own workspaces, one event per
+    control state) -- the same launches in another interleaving, so two consecutive denoiser evaluations must equal the serial
+    step bit for bit (a missing dependency or a shared workspace shows up as a difference)."""
+    from landiff_amd.dit import ControlDiTRunner
+    cfg, st = setup
+    d = cfg.dit
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, d.latent_frames, d.in_channels, d.latent_h, d.latent_w, generator=g).to(cuda)
+    ctx = torch.randn(1, d.text_len, d.text_dim, generator=g)
+    sem = (torch.randn(d.latent_frames, d.in_channels, d.latent_h, d.latent_w, generator=g) * 0.5).to(torch.bfloat16)
+    outs = []
+    for knob in ("0", "1"):
+        monkeypatch.setenv("LD_DIT_OVERLAP", knob)
+        run = ControlDiTRunner(st["dit_main"], st["dit_control"], d, cuda)
+        assert run.overlap == (knob == "1")
+        run.set_condition(ctx, sem)
+        o1, o2 = torch.empty_like(x), torch.empty_like(x)
+        run.step(x, 700, -0.6, 0.8, 3.0, o1)
+        run.step(o1, 500, -0.8, 0.6, 5.0, o2)             # the second step reads what the first wrote: cross-step ordering
+        torch.cuda.synchronize()
+        outs.append((o1.clone(), o2.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_dit_fp8_linears_close_to_bf16(cuda, setup):
     """configs[4]: the same denoiser step with e4m3 operands on the four large linears stays within the format's noise of
     the bf16 step (and is not the bf16 step)."""

@@ -18,7 +18,8 @@ torch.manual_seed(0)
 dev = "cuda"
 worst = 0.0
 # (the last three: more tiles than CUs -> persistent workgroups walk several tiles, with 1, 2 and 3 (odd) K-tiles per tile)
-for (M, N, K) in [(256, 256, 128), (300, 200, 256), (1000, 1920, 384), (5000, 512, 1920), (70000, 256, 128), (70000, 512, 64), (66000, 264, 192)]:
+for (M, N, K) in [(256, 256, 128), (300, 200, 256), (1000, 1920, 384), (5000, 512, 1920), (70000, 256, 128), (70000, 512, 64), (66000, 264, 192),
+                  (70000, 520, 256), (3000, 1000, 512)]:       # 4 and 8 K-tiles: the shapes the software-pipelined loop takes (even, >= 4)
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
     a[:, 0] += torch.arange(M, device=dev).to(torch.bfloat16) * 0.01          # transposition-detecting
@@ -169,7 +170,9 @@ def _run(snippet, env):
                                  {"LD_GEMM_TILE": "1", "LD_GEMM_M16": "0"},
                                  # the 8-phase loop (round-3 default for large problems) forced onto every size, with and
                                  # without the M-split tail launch, and with one workgroup per tile instead of persistent tiles
-                                 {"LD_GEMM_TILE": "8"}, {"LD_GEMM_TILE": "8", "LD_GEMM_MSPLIT": "0"}, {"LD_GEMM_TILE": "8", "LD_GEMM_PERSIST": "0"}])
+                                 {"LD_GEMM_TILE": "8"}, {"LD_GEMM_TILE": "8", "LD_GEMM_MSPLIT": "0"}, {"LD_GEMM_TILE": "8", "LD_GEMM_PERSIST": "0"},
+                                 # the software-pipelined loop (one barrier per K-tile, fragment reads under the wave's own MFMAs)
+                                 {"LD_GEMM_TILE": "8", "LD_GEMM_SP": "1"}, {"LD_GEMM_TILE": "8", "LD_GEMM_SP": "1", "LD_GEMM_PERSIST": "0"}])
 def test_gemm_main_loop_variants(cuda, env):
     assert _run(GEMM_SNIPPET, env) < 1e-2
 
