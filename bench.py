@@ -371,7 +371,7 @@ def main():
         keep_t, keep_a, keep_o = pipe.timings, pipe.dit.attn_events, pipe.dit.overlap
         pipe.timings, pipe.dit.attn_events, pipe.dit.gemm_events = {}, None, []
         pipe.dit.overlap = False                  # serial step: every GEMM launch has the GPU to itself while it is timed
-        one_step()
+        pipe(inp)                                 # rank 0 only: NOT one_step(), whose frame gather is a collective every rank must enter
         torch.cuda.synchronize()
         gemm_step_s = dict(pipe.timings)
         pipe.timings, pipe.dit.attn_events, pipe.dit.overlap = keep_t, keep_a, keep_o
