@@ -304,7 +304,9 @@ class LLMRunner:
         feats = self.prefix_features(text_emb, float(num_frames), motion_score)
         S = feats.shape[1] - 1
         full_len, forced, restricted, n_visual = forced_token_schedule(c, S, num_frames)
-        assert full_len <= self.Lmax
+        if full_len > self.Lmax:
+            raise ValueError(f"LLM decode of {num_frames} frames after {text_emb.shape[-2]} text tokens needs {full_len} positions; this runner "
+                             f"was built for {self.Lmax} (max_text / max_frames of LLMRunner; the reference's T5 tokenizer truncates at 512)")
         S_last = S                                         # position of the last prefilled token
         if first_frame_tokens is not None:
             assert num_frames > 1 and first_frame_tokens.numel() == c.iframe_len, "first_frame_tokens: one I frame, more frames to sample"

@@ -544,3 +544,43 @@ def test_fused_sampling_equals_torch_multinomial(cuda):
     for a, b in zip(st[0], st[1]):
         assert torch.equal(a, b)
     assert int(st[0][5]) == n - 3 and len(set(st[0][0].reshape(-1).tolist())) > 50
+
+
+@pytest.mark.parametrize("n_text", [1, 32])
+def test_llm_prompt_length_edges(cuda, setup, n_text):
+    """The shortest prompt (one T5 token) and the longest the runner was built for (max_text): prefill + decode against the oracle
+    teacher-forced on the device's history, 2x-floor rule on the CFG logits, every id flip explained; one token more is refused."""
+    from flip_audit import RecordingMultinomial, audit
+    from landiff_amd.llm import LLMRunner, forced_token_schedule
+    from oracle.llm import LLMOracle
+    cfg, st = setup
+    c = cfg.llm
+    g = torch.Generator().manual_seed(100 + n_text)
+    text = torch.randn(n_text, c.text_dim, generator=g)
+    run = LLMRunner(st["llm"], c, cuda, max_text=32, max_frames=c.segment_length)
+    gen = torch.Generator(device=cuda); gen.manual_seed(21)
+    log = []
+    codes = run.sample(text, num_frames=c.segment_length, guidance_scale=7.5, generator=gen, logits_log=log)
+    dev_logits = torch.cat(log, 0).cpu()
+    S = n_text + 3
+    full_len, forced, _, n_vis = forced_token_schedule(c, S, c.segment_length)
+    assert full_len <= run.Lmax and (n_text < 32 or full_len >= run.Lmax - 2)      # n_text = 32 fills the KV cache (two spare rows)
+    it = iter(run.out_tokens[:n_vis].cpu().tolist())
+    step_ids = [None if i in forced else next(it) for i in range(S + 1, full_len)]
+    fed = [forced[i] if i in forced else step_ids[i - S - 1] for i in range(S + 1, full_len)]
+    gen2 = torch.Generator(device=cuda); gen2.manual_seed(21)
+    mfn = RecordingMultinomial(cuda, gen2)
+    ref_codes, ref_logits = LLMOracle(st["llm"], c, torch.bfloat16).sample(text, num_frames=c.segment_length, guidance_scale=7.5, multinomial_fn=mfn,
+                                                                          teacher_tokens=torch.tensor(fed), return_logits=True)
+    _, ref32 = LLMOracle(st["llm"], c, torch.float32).sample(text, num_frames=c.segment_length, guidance_scale=7.5, return_logits=True,
+                                                             multinomial_fn=lambda p: torch.multinomial(p, 1), teacher_tokens=torch.tensor(fed))
+    scale = ref32.abs().max().item()
+    floor = (ref_logits - ref32).abs().max().item() / scale
+    err = (dev_logits - ref32).abs().max().item() / scale
+    n_cmp, flips = audit(step_ids, mfn, dev_logits, ref_logits)
+    print(f"tiny LLM, {n_text} text token(s): logits err {err:.4f} (floor {floor:.4f}); ids {n_cmp - len(flips)} / {n_cmp} equal, {len(flips)} explained flips")
+    assert err < max(2 * floor, 2e-2), (err, floor)
+    assert n_cmp == n_vis and codes.numel() == n_vis
+    if n_text == 32:
+        with pytest.raises(ValueError, match="positions"):
+            run.sample(torch.randn(35, c.text_dim), num_frames=c.segment_length, guidance_scale=7.5, generator=gen)
