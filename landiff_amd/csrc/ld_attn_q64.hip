@@ -22,6 +22,7 @@
 // V^T fragments (half h+2), so a period that starts at tile t needs K_{t+1}, K_{t+2}, V_t, V_{t+1} resident and refills the
 // other slots with K_{t+3}, K_{t+4} (K waves) and V_{t+2}, V_{t+3} (V^T waves); one workgroup barrier per period.
 #include "ld_attn.h"
+#include <atomic>
 
 namespace {
 
@@ -32,7 +33,7 @@ __device__ __forceinline__ int q64_swz_k(int r) { return ((r >> 1) & 1) | (((r >
 constexpr int Q64_NW = 4;               // waves per workgroup
 constexpr int Q64_ROWS = Q64_NW * 64;   // query rows per workgroup
 
-__device__ __forceinline__ void attn_q64_body(const AttnParams& p, int force_safe, char* smem) {   // smem: K slots 0..3 | V^T slots 0..3 | flag words
+__device__ __forceinline__ void attn_q64_body(const AttnParams& p, int force_safe, char* smem, const int bid) {   // smem: K slots 0..3 | V^T slots 0..3 | flag words; bid: remapped block index
   constexpr int NW = Q64_NW;
   constexpr int VBASE = 4 * KTILE_BYTES;
   const int tid = threadIdx.x;
@@ -44,7 +45,6 @@ __device__ __forceinline__ void attn_q64_body(const AttnParams& p, int force_saf
   const int n = (p.Nk + KT - 1) / KT;             // >= 6 (launcher)
   const int NH = 2 * n;                           // halves
 
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = bid / nqb, qblk = bid - bh * nqb;
   const int b = bh / p.H, h = bh - b * p.H;
   const bf16_t* Qb = p.Q + (long)bh * p.Npad * D;
@@ -52,6 +52,9 @@ __device__ __forceinline__ void attn_q64_body(const AttnParams& p, int force_saf
   const bf16_t* Vb = p.Vt + (long)bh * D * p.Npad;
   const int q0 = qblk * Q64_ROWS + wave * 64;
   if (qblk * Q64_ROWS >= p.Nq) return;
+#ifdef LD_Q64_TRACE   // timing builds (tools/attn_q64_trace.py): when, where and for how many cycles every workgroup ran, into kt_min
+  const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime(), t_cyc0 = __builtin_amdgcn_s_memtime();
+#endif
 
   // Q^T fragments (B operand): rows q0 + qb*16 + l16, d = ks*32 + h4*8 .. + 8, pre-multiplied by scale * log2(e)
   bf16x8_t qf[4][2];
@@ -398,12 +401,68 @@ __device__ __forceinline__ void attn_q64_body(const AttnParams& p, int force_saf
       }
     }
   }
+#ifdef LD_Q64_TRACE
+  if (p.kt_min && tid == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* rec = (unsigned long long*)p.kt_min + (long)bid * 4;
+    rec[0] = t_real0; rec[1] = __builtin_amdgcn_s_memrealtime(); rec[2] = __builtin_amdgcn_s_memtime() - t_cyc0;
+    rec[3] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 #undef FENCE
 
 __global__ __launch_bounds__(256, 2) void ld_attn_q64_kernel(AttnParams p, int force_safe) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  attn_q64_body(p, force_safe, smem);
+  attn_q64_body(p, force_safe, smem, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// ---- dynamic form: the XCDs of one chip do not run at one speed ----
+// tools/attn_q64_trace.py (profiles/r04_attn_q64_wg_trace.txt): under the package power cap the eight XCDs hold different clocks
+// (1741 ... 1876 MHz in one launch), the hardware deals workgroups to them round-robin -- 525 each -- and the launch ends when
+// the slowest XCD does (3724 us against 3482 us for the fastest).  Here one workgroup per slot (2 x CUs) PULLS query blocks: every
+// XCD owns the contiguous range of (remapped) block indices it would have been dealt, so its K / V stay in its L2, and takes
+// them in order through an agent-scope counter; an XCD that runs dry takes blocks from the others' ranges.  The counters live in
+// static device memory (the library allocates nothing), one set per launch in flight (Q64_QSETS, chosen round-robin by the
+// host), zeroed again by the last workgroup to leave.  Same per-block arithmetic: bit-identical output.
+constexpr int Q64_QSETS = 64;
+__device__ unsigned g_q64_queue[Q64_QSETS][16];          // [set][0..7]: next block of XCD x's range, [8]: workgroups that left
+
+__global__ __launch_bounds__(256, 2) void ld_attn_q64_dyn_kernel(AttnParams p, int force_safe, int total, int set) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* bcast = (int*)(smem + 8 * KTILE_BYTES + 32);
+  unsigned* Q = g_q64_queue[set];
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  const int per = total / 8, rem = total % 8;            // xcd_remap: XCD x owns [base(x), base(x) + cnt(x))
+  auto base = [&](int x) { return x < rem ? x * (per + 1) : rem * (per + 1) + (x - rem) * per; };
+  auto cnt = [&](int x) { return per + (x < rem ? 1 : 0); };
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int bid = -1;
+      for (int kx = 0; kx < 8 && bid < 0; ++kx) {        // own range first, then the neighbours'
+        const int x = (int)((xcc + kx) & 7u);
+        if (__hip_atomic_load(&Q[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cnt(x)) continue;
+        const unsigned i = __hip_atomic_fetch_add(&Q[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i < (unsigned)cnt(x)) bid = base(x) + (int)i;
+      }
+      bcast[0] = bid;
+    }
+    __syncthreads();
+    const int bid = bcast[0];
+    __syncthreads();
+    if (bid < 0) break;
+    attn_q64_body(p, force_safe, smem, bid);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const unsigned left = __hip_atomic_fetch_add(&Q[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == gridDim.x - 1)                            // everybody else has stopped pulling: ready for the set's next launch
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(&Q[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace
@@ -417,6 +476,24 @@ int ld_attn_q64_launch(const AttnParams& p, hipStream_t st) {
   if (safe < 0) { const char* e = getenv("LD_ATTN_SAFE"); safe = e ? atoi(e) : 0; }
   static thread_local LdSmemCache cache{};
   if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_q64_kernel, SMEM, &cache)) return rc;
+  // The dynamic form (default) for grids of at least four rounds of the chip's slots; LD_ATTN_DYN=0 (read per call, so that one
+  // process can time both forms alternately): the hardware's round-robin dispatch of one workgroup per query block.
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    slots = 2 * cus;
+  }
+  const char* ed = getenv("LD_ATTN_DYN");
+  const int total = (int)((long)p.B * p.H * ((p.Npad + Q64_ROWS - 1) / Q64_ROWS));
+  if ((ed ? atoi(ed) : 1) > 0 && !safe && total >= 4 * slots) {
+    static thread_local LdSmemCache cache_d{};
+    static std::atomic<unsigned> seq{0};
+    if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_q64_dyn_kernel, SMEM, &cache_d)) return rc;
+    ld_attn_set_last_kernel("ld_attn_q64_dyn_kernel");
+    hipLaunchKernelGGL(ld_attn_q64_dyn_kernel, dim3((unsigned)slots), dim3(256), SMEM, st, p, safe, total, (int)(seq.fetch_add(1) % Q64_QSETS));
+    return ld_check_launch("ld_attn_fwd_bf16(q64 dynamic)");
+  }
   ld_attn_set_last_kernel(safe ? "ld_attn_q64_kernel[safe pass forced]" : "ld_attn_q64_kernel");
   dim3 grid((unsigned)((long)p.B * p.H * ((p.Npad + Q64_ROWS - 1) / Q64_ROWS)));
   hipLaunchKernelGGL(ld_attn_q64_kernel, grid, dim3(256), SMEM, st, p, safe);

@@ -135,3 +135,51 @@ def test_attn_q128_equals_q64_bit_for_bit_in_process(cuda, monkeypatch):
         outs.append(out); names.append(_last_kernel())
     assert names == ["ld_attn_q64_kernel", "ld_attn_q128_kernel"], names
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- the dynamic form of the 64-row kernel (ld_attn_q64_dyn_kernel: one workgroup per slot pulls query blocks, XCD by XCD) ----
+def _qkv(cuda, B, H, N, seed):
+    g = torch.Generator(device=cuda).manual_seed(seed)
+    Npad = (N + 127) // 128 * 128
+    q = torch.zeros(B, H, Npad, 64, device=cuda, dtype=torch.bfloat16); k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, 64, Npad, device=cuda, dtype=torch.bfloat16)
+    q[:, :, :N] = torch.randn(B, H, N, 64, device=cuda, generator=g).to(torch.bfloat16)
+    k[:, :, :N] = torch.randn(B, H, N, 64, device=cuda, generator=g).to(torch.bfloat16)
+    vt[:, :, :, :N] = torch.randn(B, H, 64, N, device=cuda, generator=g).to(torch.bfloat16)
+    return q, k, vt
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 30, 17776), (1, 40, 13100)])
+def test_attn_dynamic_queue_equals_round_robin_dispatch(cuda, monkeypatch, B, H, N):
+    """Grids of >= four rounds take the dynamic form by default; LD_ATTN_DYN=0 (read per call) is the hardware's own dispatch of
+    one workgroup per query block.  Same per-block code: identical bits.  The queue counters are static device memory in 64
+    sets, re-zeroed by the last workgroup to leave: 70 launches in a row, and launches on two streams at once, stay identical."""
+    from landiff_amd import ops
+    q, k, vt = _qkv(cuda, B, H, N, seed=N)
+    monkeypatch.setenv("LD_ATTN_DYN", "0")
+    ref = torch.zeros(B, N, H * 64, device=cuda, dtype=torch.bfloat16)
+    ops.attn_fwd(q, k, vt, ref, N, N, 0.125)
+    assert _last_kernel() == "ld_attn_q64_kernel"
+    monkeypatch.delenv("LD_ATTN_DYN")
+    out = torch.zeros_like(ref)
+    for i in range(70):
+        out.zero_()
+        ops.attn_fwd(q, k, vt, out, N, N, 0.125)
+        if i in (0, 1, 63, 64, 69):
+            assert torch.equal(out, ref), i
+    assert _last_kernel() == "ld_attn_q64_dyn_kernel"
+    q2, k2, vt2 = _qkv(cuda, B, H, N, seed=N + 1)
+    monkeypatch.setenv("LD_ATTN_DYN", "0")
+    ref2 = torch.zeros_like(ref)
+    ops.attn_fwd(q2, k2, vt2, ref2, N, N, 0.125)
+    monkeypatch.delenv("LD_ATTN_DYN")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1 = [torch.zeros_like(ref) for _ in range(4)]; o2 = [torch.zeros_like(ref) for _ in range(4)]
+    torch.cuda.synchronize()
+    for i in range(4):                       # two launches in flight together, each pulling from its own counter set
+        with torch.cuda.stream(s1):
+            ops.attn_fwd(q, k, vt, o1[i], N, N, 0.125)
+        with torch.cuda.stream(s2):
+            ops.attn_fwd(q2, k2, vt2, o2[i], N, N, 0.125)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in o1) and all(torch.equal(o, ref2) for o in o2)

@@ -19,7 +19,7 @@ q = torch.randn(B, H, Npad, 64, device="cuda").to(torch.bfloat16)
 k = torch.randn(B, H, Npad, 64, device="cuda").to(torch.bfloat16)
 vt = torch.randn(B, H, 64, Npad, device="cuda").to(torch.bfloat16)
 out = torch.empty(B, N, H * 64, device="cuda", dtype=torch.bfloat16)
-arms = [("q64", {"LD_ATTN_Q128": "0"}), ("q128 npre44", {"LD_ATTN_Q128": "1", "LD_ATTN_NPRE": "44"}),
+arms = [("q64", {"LD_ATTN_Q128": "0", "LD_ATTN_DYN": "0"}), ("q64 dyn", {"LD_ATTN_Q128": "0", "LD_ATTN_DYN": "1"}), ("q128 npre44", {"LD_ATTN_Q128": "1", "LD_ATTN_NPRE": "44"}),
         ("q128 npre36", {"LD_ATTN_Q128": "1", "LD_ATTN_NPRE": "36"}), ("q128 npre52", {"LD_ATTN_Q128": "1", "LD_ATTN_NPRE": "52"}),
         ("q128 s1 n36", {"LD_ATTN_Q128": "1", "LD_ATTN_NPRE": "1036"}), ("q128 s1 n40", {"LD_ATTN_Q128": "1", "LD_ATTN_NPRE": "1040"})]
 if os.environ.get("ARMS"):
