@@ -768,6 +768,10 @@ __device__ __forceinline__ void stage_pieces(const bf16_t* base, int bytes, char
 // Measured (tools/gemm_ab.py, profiles/r03_gemm_*): bit-identical outputs; see DESIGN.md section 4.
 // ------------------------------------------------------------------------------------------------
 constexpr int LD_LDS_TOTAL = 160 * 1024;
+#ifdef LD_GEMM_TRACE   // timing builds (tools/gemm_tile_trace.py): per tile of ld_gemm8p_kernel start / end of main loop / end, XCC_ID, HW_ID
+__device__ unsigned long long* g_gemm_trace = nullptr;     // [0]: record counter, then 4 words per record
+__device__ int g_gemm_trace_cap = 0;
+#endif
 
 template <bool CONV, int EPI>
 __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
@@ -952,6 +956,10 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
   for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
     int m0, n0;
     tile_origin(v, m0, n0);
+#ifdef LD_GEMM_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tr1 = 0;
+#endif
     src = tile_src(m0, n0);
     wave_live = n0 + wc * 64 < p.N;
     if (CONV) set_offsets(m0, false);
@@ -981,6 +989,9 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
     if (kt < nk) ktile(I0{}, kt);
     if (wr == 0) bar();
     __syncthreads();                                      // every fragment read of this tile has been waited for
+#ifdef LD_GEMM_TRACE
+    tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- epilogue, with the next tile's first K-tile requested from inside it ----
     const int vn = v + gridDim.x;
@@ -1000,6 +1011,19 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
     if constexpr (EPI == EPI_QKV) qkv_epilogue16<4>(p, acc, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
     else gemm_epilogue16<4, EPI, 4, SWAPACC>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
     hook();
+#ifdef LD_GEMM_TRACE
+    if (tid == 0 && g_gemm_trace) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      const unsigned long long slot = __hip_atomic_fetch_add(g_gemm_trace, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((long long)slot < g_gemm_trace_cap) {
+        unsigned long long* rec = g_gemm_trace + 1 + slot * 4;
+        rec[0] = tr0; rec[1] = tr1; rec[2] = __builtin_amdgcn_s_memrealtime();
+        rec[3] = ((unsigned long long)(xcc & 0xf) << 48) | ((unsigned long long)(hw & 0xffff) << 32) | (unsigned)v;
+      }
+    }
+#endif
     if (vn < ntiles) __syncthreads();                     // the staging region is free again before buffer-1 slots are re-staged
   }
 }
@@ -1989,3 +2013,12 @@ LD_API int ld_gemm_mxfp8(const void* A8, int64_t lda, const void* scales_a, cons
   }
   return launch_f8(p, (hipStream_t)stream);
 }
+
+#ifdef LD_GEMM_TRACE
+LD_API int ld_gemm_trace_set(void* buf, int64_t capacity_records) {
+  unsigned long long* b = (unsigned long long*)buf; int cap = (int)capacity_records;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &b, sizeof(b)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace_cap), &cap, sizeof(cap)) != hipSuccess) return 1;
+  return 0;
+}
+#endif
