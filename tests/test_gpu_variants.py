@@ -256,3 +256,14 @@ def test_bench_rccl_path_single_rank(cuda):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["unit"] == "frames/s"
+    # the line's contract: the driver's keys, the roofline object of the dominant kernel, the calibration of the box, per-rank reports
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "roofline_stages", "calibration", "per_rank"):
+        assert k in res, k
+    assert res["scaling"] == "weak" and res["higher_is_better"] is True and res["vs_baseline"] is None and res["data"] == "synthetic"
+    assert "workload" in res["config"] and "model" not in res["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms"):
+        assert k in res["roofline"], k
+    assert res["roofline"]["bound"] == "mfma" and res["roofline"]["frac"] == pytest.approx(res["roofline"]["achieved"] / res["roofline"]["peak"], abs=1e-3)
+    assert res["calibration"]["mfma_tflops"] > 100 and res["calibration"]["hbm_gbs"] > 500
+    assert len(res["per_rank"]["frames_per_s"]) == 1
