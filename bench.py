@@ -213,7 +213,7 @@ def cpu_baseline(cfg):
         orc = DiTOracle(init_state(dit_spec(d1, False), 1), d1, False, torch.float32)
         h = torch.randn(2, d1.seq_len, d1.hidden)
         emb = torch.randn(2, d1.time_embed_dim)
-        t0 = time.perf_counter(); orc.layer(0, h, emb); out["dit_layer_s"] = time.perf_counter() - t0
+        out["dit_layer_s"] = _median(lambda: orc.layer(0, h, emb), 3)
         del orc, h
         l1 = dataclasses.replace(cfg.llm, num_layers=1)
         lo = LLMOracle(init_state(llm_spec(l1), 2), l1, torch.float32)
@@ -230,7 +230,7 @@ def cpu_baseline(cfg):
         c3, s3 = rope3d_table(t1)
         fid = torch.from_numpy(frame_ids(t1))
         mask = (fid[None, :] <= fid[:, None])[None, None]
-        t0 = time.perf_counter(); to.titok_block(0, xt, c3[None], s3[None], mask); out["titok_layer_s"] = time.perf_counter() - t0
+        out["titok_layer_s"] = _median(lambda: to.titok_block(0, xt, c3[None], s3[None], mask), 3)
         del to, mask
         vc = VAEConfig()
         C, T, H, W = vc.ch, 2, 480, 720
@@ -238,23 +238,59 @@ def cpu_baseline(cfg):
         vo = VAEDecoderOracle(init_state(_res3d(p, C, C, vc.z_channels), 4), vc, torch.float32)
         xv = torch.randn(1, C, T, H, W)
         zq = torch.randn(1, vc.z_channels, 1, 60, 90)
-        t0 = time.perf_counter(); vo.resblock(xv, zq, p, C, C, True); dt = time.perf_counter() - t0
+        dt = _median(lambda: vo.resblock(xv, zq, p, C, C, True), 3)
         out["vae_resblock_s"] = dt
         out["vae_tflops"] = 2 * (2.0 * T * H * W * C * C * 27) / dt / 1e12
     d, l = cfg.dit, cfg.llm
     total = (out["dit_layer_s"] * (d.layers_main + d.layers_control) * cfg.sampler.num_steps
              + out["llm_layer_s"] * l.num_layers * 1244 + out["titok_layer_s"] * cfg.tok.layers + VAE_TFLOP / out["vae_tflops"])
     frames = 4 * d.latent_frames - 3
-    return {"value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port", **host_cpu(),
+            "threads_note": "torch intra-op threads = min(os.cpu_count(), 64): the oracle's CPU kernels stop scaling well below the host's core count",
             "extrapolated_seconds_per_video": round(total, 1),
             "config0_end_to_end": {"seconds": round(out["config0_s"], 2), "frames": out["config0_frames"],
                                    "frames_per_s": round(out["config0_frames"] / out["config0_s"], 3),
                                    "workload": "BASELINE configs[0]: random-init tiny DiT, 8 latent frames, 64x64 latent, 2 DDIM steps, whole pipeline"},
-            "sample": ("oracle fp32 on host cores: configs[0] end to end %.1fs; full shapes: 1 DiT layer-call (B=2,N=17776) %.1fs, 1 LLM decode "
-                       "layer %.4fs (median of 5), 1 TiTok layer %.1fs, 1 level-0 VAE resblock (2 frames 480x720) %.1fs = %.2f TFLOP/s; "
+            "sample": ("oracle fp32 on host cores: configs[0] end to end %.1fs (one run); full shapes: 1 DiT layer-call (B=2,N=17776) %.1fs, 1 LLM decode "
+                       "layer %.4fs (median of 5), 1 TiTok layer %.1fs, 1 level-0 VAE resblock (2 frames 480x720) %.1fs = %.2f TFLOP/s (medians of 3); "
                        "extrapolated x(45x50), x(24x1244), x12, 315 TFLOP -> %.0f s/video"
                        % (out["config0_s"], out["dit_layer_s"], out["llm_layer_s"], out["titok_layer_s"], out["vae_resblock_s"],
                           out["vae_tflops"], total))}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one (which has not touched the
+    GPU and never will -- an exec of a GPU-initialised process is what the pool forbids), one per GPU, through
+    torch.distributed.run on the loopback address and a free port.  The children inherit stdout / stderr, so rank 0's JSON line is
+    this command's JSON line; the return code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))       # torchrun would force 1: starves the CPU-side packing
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"bench.py: no launcher in the environment, starting {n} rank(s): {' '.join(cmd)}", file=sys.stderr, flush=True)
+    if os.environ.get("LD_BENCH_DRY_SPAWN") == "1":          # (tests on a box without GPUs: show the command, start nothing)
+        return 0
+    return subprocess.run(cmd, env=env).returncode
+
+
+def host_cpu() -> dict:
+    """Model string and counts of the host CPU the baseline ran on (BASELINE.md section 3 asks for them next to the number)."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "cores_allowed": aff}
 
 
 def llm_step_bytes(c) -> float:
@@ -287,12 +323,14 @@ def main():
     if args.fp8_gemm and not args.stream_chunks:
         raise SystemExit("--fp8-gemm belongs to the streaming long-video configuration (BASELINE configs[4]): add --stream-chunks N")
 
+    if "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("LD_BENCH_FORCE_DIST") == "1"):
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N-GPU runs with "
-                         "`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...`")
+        raise SystemExit(f"--gpus {args.gpus} but this process is rank {rank} of WORLD_SIZE={world}: the launcher's --nproc-per-node "
+                         "and --gpus must agree (plain `python bench.py --gpus N` starts its own N ranks)")
     import torch.distributed as dist
     from landiff_amd.pipeline import gather_rank_reports, pin_rank_cores
     my_cores = pin_rank_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
@@ -385,6 +423,9 @@ def main():
         # with it and its event-to-event time is not the kernel's own: the kernel's duration is taken from the launches that run
         # alone -- the main layers behind the last control state, 14 of a step's 45 -- all of them inside the timed region.
         ev = [(a, b) for a, b, solo in ev_all if solo]
+        solo_rule = pipe.dit.overlap
+        if not ev:                    # (tiny configs: no main layer lies behind the last control state) every launch, and say so
+            ev, solo_rule = [(a, b) for a, b, _ in ev_all], False
         attn_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
         attn_all_ms = sum(a.elapsed_time(b) for a, b, _ in ev_all) / max(len(ev_all), 1)
         flops = 4.0 * 2 * d.heads * d.seq_len * d.seq_len * d.head_dim      # algorithmic FLOPs of one launch
@@ -402,10 +443,15 @@ def main():
                      "launches": len(ev), "launches_total": len(ev_all),
                      "avg_launch_ms": round(attn_ms, 4), "avg_launch_ms_all_incl_overlapped": round(attn_all_ms, 4),
                      "overlap": ("control chain on a second stream (LD_DIT_OVERLAP=1): `achieved` is over the launches that run alone"
-                                 if pipe.dit.overlap else "serial step: every launch runs alone")}
+                                 if solo_rule else
+                                 "control chain on a second stream and NO launch runs alone in this configuration: `achieved` is over all launches, "
+                                 "whose event intervals include time shared with the other chain" if pipe.dit.overlap else
+                                 "serial step: every launch runs alone")}
         # ---- per-stage achieved vs peak (rank 0) ----------------------------------------------------
         stages = {"dit_attention": {k: attn_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
-        stages["dit_attention"]["seconds_per_step"] = round(attn_ms * 1e-3 * len(ev_all) / args.steps, 3)    # (kernel time x all launches)
+        stages["dit_attention"]["seconds_per_step"] = round(attn_ms * 1e-3 * len(ev_all) / args.steps, 3)
+        stages["dit_attention"]["what"] = ("the kernel's own duration (launches that run alone) x all launches of a step: GPU time, not wall time -- "
+                                           "overlapped launches take longer on the wall (avg_launch_ms_all_incl_overlapped)")
         gev = pipe.dit.gemm_events
         if gev and not args.fp8_gemm:          # (the e4m3 linears are not bracketed: only the bf16 control zero-linears would be counted)
             g_s = sum(a.elapsed_time(b) for a, b, _ in gev) * 1e-3
@@ -475,6 +521,7 @@ def main():
             res["stage_seconds_rank0"] = {k: round(v, 3) for k, v in stage_s.items()}
         if world > 1 or use_dist:
             fps = [r["frames_per_s"] for r in reports]
+            res["n_ranks_seen"] = dist.get_world_size()          # what RCCL itself says the job size was
             res["per_rank"] = {"frames_per_s_min": min(fps), "frames_per_s_max": max(fps), "frames_per_s": fps,
                                "stage_seconds": [r["stage_seconds"] for r in reports], "cores_per_rank": [r["cores"] for r in reports]}
         if not args.no_cpu_baseline and world == 1:

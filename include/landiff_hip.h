@@ -7,6 +7,10 @@
  *   - the caller owns every buffer including workspaces; the library never allocates,
  *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); all work is
  *     asynchronous on it, no internal synchronisation, re-entrant per stream,
+ *   - the library keeps ONE piece of state: the work-queue counters of the dynamic attention launch (64 sets of
+ *     64 bytes in static device memory, one copy per device; see ld_attn_fwd_bf16 and ld_reset).  A set belongs to one
+ *     (device, stream) pair and is zeroed on the launch stream before every use, so launches on different streams never
+ *     share one and a failed launch leaves nothing behind; everything else is stateless,
  *   - return 0 on success, negative on error; ld_last_error() gives the thread-local message,
  *   - bf16 tensors are raw uint16 bit patterns; "f32" means IEEE float.
  */
@@ -20,8 +24,9 @@ extern "C" {
 
 /* Bumped whenever a signature changes or an entry point is added / removed (2: ld_groupnorm_stats took its `partials`
  * argument, ld_gemm_qkv_heads / ld_llm_sample_advance / ld_groupnorm_stats_blocks / ld_attn_last_kernel were added).  A caller
- * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does). */
-#define LD_ABI_VERSION 5
+ * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does).
+ * 6: ld_reset and ld_attn_queue_poke were added. */
+#define LD_ABI_VERSION 6
 
 int ld_version(void);
 const char* ld_last_error(void);
@@ -143,12 +148,25 @@ int ld_layernorm_mxfp8(const void* x, int64_t ldx, const void* w, const void* b,
  * carry INT32_MAX; kt_min/kt_max are the per-64-key-tile min/max of fid_k.
  * Replaces sat attention_fn_default/F.scaled_dot_product_attention behind AdaLNMixin.attention_fn
  * (landiff/diffusion/dit_video_concat.py:636-664) and flex_attention with VideoDecoderMask
- * (landiff/tokenizer/modules/blocks.py:172-212, flex_attention_mask.py:193-335). */
+ * (landiff/tokenizer/modules/blocks.py:172-212, flex_attention_mask.py:193-335).
+ * Large unmasked problems (>= 4 rounds of 2 workgroups per CU) run as a dynamic launch whose workgroups pull query blocks
+ * through per-XCD counters.  The counter set is chosen by (current device, stream): the first 64 streams of a device that
+ * launch attention own one each, further streams -- and any stream that is being captured into a graph -- take the static
+ * launch of the same kernel body (bit-identical output).  The set is zeroed on `stream` right before the kernel. */
 int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
                      int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
                      int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
                      const int32_t* fid_q, const int32_t* fid_k,
                      const int32_t* kt_min, const int32_t* kt_max, void* stream);
+
+/* Forgets the stream -> counter-set assignments of the current device and zeroes its sets (asynchronously on `stream`).
+ * Only for a process that keeps creating streams, or after a device error: the caller guarantees that no ld_attn_fwd_bf16
+ * launch of this device is enqueued or running on any other stream. */
+int ld_reset(void* stream);
+
+/* Test hook: fills counter set `set` (all 64 when set < 0) of the current device with `value`, as a launch that died
+ * mid-flight could leave it.  Later launches must be unaffected (tests/test_gpu_attn.py). */
+int ld_attn_queue_poke(int32_t set, uint32_t value, void* stream);
 
 /* Name of the kernel the calling thread's last ld_attn_fwd_bf16 launched ("" before the first call): the launcher picks
  * by shape and tuning environment, and measurement code must label what actually ran. */

@@ -3,6 +3,7 @@
 #include "../../include/landiff_hip.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -32,6 +33,15 @@ int ld_ensure_dyn_smem(const void* kernel, size_t bytes, LdSmemCache* cache) {
     return ld_set_error(LD_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) on device %d: %s", bytes, dev, hipGetErrorString(e));
   if (cached) cache->bytes[dev] = bytes;
   return LD_OK;
+}
+
+int ld_knob(const char* name, int dflt, int* cache) {
+  static const int tuning = [] { const char* t = getenv("LD_TUNING"); return t ? atoi(t) : 0; }();
+  if (!tuning && *cache != LD_KNOB_UNSET) return *cache;
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : dflt;
+  *cache = v;                                                  // racing first calls write the same value
+  return v;
 }
 
 LD_API int ld_version(void) { return LD_ABI_VERSION; }

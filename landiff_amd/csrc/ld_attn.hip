@@ -382,11 +382,10 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   // LD_ATTN_Q64=0 (tuning knob): the 32-query-row wave tile of ld_attn_p16.hip instead of the 64-row one of ld_attn_q64.hip
   static const int q64 = getenv("LD_ATTN_Q64") ? atoi(getenv("LD_ATTN_Q64")) : 1;
   // LD_ATTN_Q128 (tuning knob): 1 = the 128-query-row, one-wave-per-SIMD tile of ld_attn_q128.hip (512 rows per workgroup: only
-  // for problems with enough query rows to fill the chip with such workgroups)
-  // for problems with enough query rows to fill the chip with such workgroups; 2: every unmasked problem).  Read on every call
-  // (a getenv is nothing next to a launch) so that one process can time both tiles alternately (tools/attn_ab.py).
-  const char* e128 = getenv("LD_ATTN_Q128");
-  const int q128 = e128 ? atoi(e128) : 0;
+  // for problems with enough query rows to fill the chip with such workgroups); 2 = every unmasked problem of >= 6 key tiles.
+  // Like every knob it is read once, or per call under LD_TUNING=1 (ld_common.h) so that one process can time both tiles.
+  static int k_q128 = LD_KNOB_UNSET;
+  const int q128 = ld_knob("LD_ATTN_Q128", 0, &k_q128);
   if (var == 0 && !fid_k && nkt >= 6 && (q128 == 2 || (q128 == 1 && B * H * ((Npad + 511) / 512) >= 512)))
     return ld_attn_q128_launch(p, st);
   if (var == 0 && !fid_k && nkt >= 6 && q64) return ld_attn_q64_launch(p, st);

@@ -504,8 +504,8 @@ int ld_attn_q128_launch(const AttnParams& p, hipStream_t st) {
   constexpr int SMEM = 8 * KTILE_BYTES + 64;
   static int safe = -1;
   if (safe < 0) { const char* e = getenv("LD_ATTN_SAFE"); safe = e ? atoi(e) : 0; }
-  const char* ne = getenv("LD_ATTN_NPRE");            // per call, like LD_ATTN_Q128 (ld_attn.hip)
-  const int npre = ne ? atoi(ne) : 44;
+  static int k_npre = LD_KNOB_UNSET;
+  const int npre = ld_knob("LD_ATTN_NPRE", 44, &k_npre);
   static thread_local LdSmemCache c44{}, c36{}, c52{}, cs1{}, cs2{};
   dim3 grid((unsigned)((long)p.B * p.H * ((p.Npad + Q128_ROWS - 1) / Q128_ROWS)));
   if (npre != 44) {

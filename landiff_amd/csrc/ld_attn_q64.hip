@@ -22,7 +22,7 @@
 // V^T fragments (half h+2), so a period that starts at tile t needs K_{t+1}, K_{t+2}, V_t, V_{t+1} resident and refills the
 // other slots with K_{t+3}, K_{t+4} (K waves) and V_{t+2}, V_{t+3} (V^T waves); one workgroup barrier per period.
 #include "ld_attn.h"
-#include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -424,11 +424,22 @@ __global__ __launch_bounds__(256, 2) void ld_attn_q64_kernel(AttnParams p, int f
 // (1741 ... 1876 MHz in one launch), the hardware deals workgroups to them round-robin -- 525 each -- and the launch ends when
 // the slowest XCD does (3724 us against 3482 us for the fastest).  Here one workgroup per slot (2 x CUs) PULLS query blocks: every
 // XCD owns the contiguous range of (remapped) block indices it would have been dealt, so its K / V stay in its L2, and takes
-// them in order through an agent-scope counter; an XCD that runs dry takes blocks from the others' ranges.  The counters live in
-// static device memory (the library allocates nothing), one set per launch in flight (Q64_QSETS, chosen round-robin by the
-// host), zeroed again by the last workgroup to leave.  Same per-block arithmetic: bit-identical output.
+// them in order through an agent-scope counter; an XCD that runs dry takes blocks from the others' ranges.  Same per-block
+// arithmetic: bit-identical output.
+//
+// The counters are the ONE piece of state this library keeps: Q64_QSETS sets of eight words in static device memory (one copy
+// per device, the library still allocates nothing).  What makes a set safe to use:
+//   * a set belongs to one (device, stream) pair for the life of the process (q64_set_for): two launches can only share a set
+//     if they are on the same stream, where they run one after the other;
+//   * the launcher zeroes the set ON THE LAUNCH STREAM right before the kernel (hipMemsetAsync of 64 bytes), so whatever an
+//     earlier launch left there -- an aborted kernel, a poisoned set (ld_attn_queue_poke) -- cannot reach this one; the kernel
+//     itself never needs to clean up;
+//   * a launch that cannot get a set of its own -- more than Q64_QSETS streams of one device have launched attention since the
+//     last ld_reset(), or the stream is being captured into a graph (a replayed graph may run on any stream, next to anything)
+//     -- takes the static kernel: the same bits, the hardware's own dispatch.
 constexpr int Q64_QSETS = 64;
-__device__ unsigned g_q64_queue[Q64_QSETS][16];          // [set][0..7]: next block of XCD x's range, [8]: workgroups that left
+constexpr int Q64_MAXDEV = 16;
+__device__ unsigned g_q64_queue[Q64_QSETS][16];          // [set][0..7]: next block of XCD x's range (64 bytes per set)
 
 __global__ __launch_bounds__(256, 2) void ld_attn_q64_dyn_kernel(AttnParams p, int force_safe, int total, int set) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -458,44 +469,104 @@ __global__ __launch_bounds__(256, 2) void ld_attn_q64_dyn_kernel(AttnParams p, i
     attn_q64_body(p, force_safe, smem, bid);
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const unsigned left = __hip_atomic_fetch_add(&Q[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == gridDim.x - 1)                            // everybody else has stopped pulling: ready for the set's next launch
-      for (int i = 0; i < 9; ++i) __hip_atomic_store(&Q[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void ld_q64_queue_fill_kernel(int set, unsigned value) {
+  const int s = blockIdx.x;
+  if ((set < 0 || s == set) && threadIdx.x < 16) g_q64_queue[s][threadIdx.x] = value;
+}
+
+// ---- host side of the counter sets ----
+struct Q64Owner { int dev; hipStream_t st; };
+std::mutex g_q64_mu;
+Q64Owner g_q64_owner[Q64_MAXDEV][Q64_QSETS];
+int g_q64_owners[Q64_MAXDEV];                            // sets handed out per device
+unsigned* g_q64_base[Q64_MAXDEV];                        // device address of g_q64_queue, per device
+int g_q64_slots[Q64_MAXDEV];                             // 2 x CUs, per device
+
+// the set of (dev, st), handing out a new one on first sight; -1 when the device's sets are all taken
+int q64_set_for(int dev, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_q64_mu);
+  const int n = g_q64_owners[dev];
+  for (int i = 0; i < n; ++i) if (g_q64_owner[dev][i].st == st) return i;
+  if (n >= Q64_QSETS) return -1;
+  g_q64_owner[dev][n] = Q64Owner{dev, st};
+  g_q64_owners[dev] = n + 1;
+  return n;
+}
+
+int q64_device_info(int* dev_out, unsigned** base_out, int* slots_out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return ld_set_error(LD_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= Q64_MAXDEV) { *dev_out = -1; return LD_OK; }         // no dynamic form on such a device
+  std::lock_guard<std::mutex> lk(g_q64_mu);
+  if (!g_q64_base[dev]) {
+    void* sym = nullptr;
+    e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_q64_queue));
+    if (e != hipSuccess) return ld_set_error(LD_ERR_LAUNCH, "hipGetSymbolAddress(g_q64_queue) on device %d: %s", dev, hipGetErrorString(e));
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    g_q64_slots[dev] = 2 * cus;
+    g_q64_base[dev] = (unsigned*)sym;
   }
+  *dev_out = dev; *base_out = g_q64_base[dev]; *slots_out = g_q64_slots[dev];
+  return LD_OK;
 }
 
 }  // namespace
 
 void ld_attn_set_last_kernel(const char* name);   // ld_attn.hip
 
-// LD_ATTN_SAFE=1 forces the running-max pass (testing).
+// LD_ATTN_SAFE=1 forces the running-max pass (testing).  LD_ATTN_DYN=0: the hardware's round-robin dispatch of one workgroup per
+// query block instead of the dynamic form (the default for grids of at least four rounds of the chip's slots).
 int ld_attn_q64_launch(const AttnParams& p, hipStream_t st) {
   constexpr int SMEM = 8 * KTILE_BYTES + 64;
-  static int safe = -1;
-  if (safe < 0) { const char* e = getenv("LD_ATTN_SAFE"); safe = e ? atoi(e) : 0; }
+  static int k_safe = LD_KNOB_UNSET, k_dyn = LD_KNOB_UNSET;
+  const int safe = ld_knob("LD_ATTN_SAFE", 0, &k_safe);
   static thread_local LdSmemCache cache{};
   if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_q64_kernel, SMEM, &cache)) return rc;
-  // The dynamic form (default) for grids of at least four rounds of the chip's slots; LD_ATTN_DYN=0 (read per call, so that one
-  // process can time both forms alternately): the hardware's round-robin dispatch of one workgroup per query block.
-  static int slots = 0;
-  if (slots == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    slots = 2 * cus;
-  }
-  const char* ed = getenv("LD_ATTN_DYN");
   const int total = (int)((long)p.B * p.H * ((p.Npad + Q64_ROWS - 1) / Q64_ROWS));
-  if ((ed ? atoi(ed) : 1) > 0 && !safe && total >= 4 * slots) {
-    static thread_local LdSmemCache cache_d{};
-    static std::atomic<unsigned> seq{0};
-    if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_q64_dyn_kernel, SMEM, &cache_d)) return rc;
-    ld_attn_set_last_kernel("ld_attn_q64_dyn_kernel");
-    hipLaunchKernelGGL(ld_attn_q64_dyn_kernel, dim3((unsigned)slots), dim3(256), SMEM, st, p, safe, total, (int)(seq.fetch_add(1) % Q64_QSETS));
-    return ld_check_launch("ld_attn_fwd_bf16(q64 dynamic)");
+  if (ld_knob("LD_ATTN_DYN", 1, &k_dyn) > 0 && !safe) {
+    int dev = -1, slots = 0; unsigned* base = nullptr;
+    if (int rc = q64_device_info(&dev, &base, &slots)) return rc;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (dev >= 0 && total >= 4 * slots && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+      const int set = q64_set_for(dev, st);
+      if (set >= 0) {
+        static thread_local LdSmemCache cache_d{};
+        if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_q64_dyn_kernel, SMEM, &cache_d)) return rc;
+        hipError_t e = hipMemsetAsync(base + set * 16, 0, 64, st);
+        if (e != hipSuccess) return ld_set_error(LD_ERR_LAUNCH, "ld_attn_fwd_bf16(q64 dynamic): zeroing counter set %d: %s", set, hipGetErrorString(e));
+        ld_attn_set_last_kernel("ld_attn_q64_dyn_kernel");
+        hipLaunchKernelGGL(ld_attn_q64_dyn_kernel, dim3((unsigned)slots), dim3(256), SMEM, st, p, safe, total, set);
+        return ld_check_launch("ld_attn_fwd_bf16(q64 dynamic)");
+      }
+    }
   }
   ld_attn_set_last_kernel(safe ? "ld_attn_q64_kernel[safe pass forced]" : "ld_attn_q64_kernel");
-  dim3 grid((unsigned)((long)p.B * p.H * ((p.Npad + Q64_ROWS - 1) / Q64_ROWS)));
-  hipLaunchKernelGGL(ld_attn_q64_kernel, grid, dim3(256), SMEM, st, p, safe);
+  hipLaunchKernelGGL(ld_attn_q64_kernel, dim3((unsigned)total), dim3(256), SMEM, st, p, safe);
   return ld_check_launch("ld_attn_fwd_bf16(q64)");
+}
+
+// Forget which stream owns which counter set on the current device and zero the sets (on `stream`).  The caller guarantees that no
+// ld_attn_fwd_bf16 launch of this device is in flight or enqueued on another stream (synchronise first): afterwards the next 64
+// streams to launch attention get sets again.  Needed only by a process that keeps creating streams, or to put the library back
+// into its initial state after a device error; an ordinary caller never has to call it.
+LD_API int ld_reset(void* stream) {
+  int dev = -1, slots = 0; unsigned* base = nullptr;
+  if (int rc = q64_device_info(&dev, &base, &slots)) return rc;
+  if (dev < 0) return LD_OK;
+  { std::lock_guard<std::mutex> lk(g_q64_mu); g_q64_owners[dev] = 0; }
+  hipError_t e = hipMemsetAsync(base, 0, sizeof(unsigned) * Q64_QSETS * 16, (hipStream_t)stream);
+  if (e != hipSuccess) return ld_set_error(LD_ERR_LAUNCH, "ld_reset: %s", hipGetErrorString(e));
+  return LD_OK;
+}
+
+// Test hook: fill counter set `set` (every set when set < 0) of the current device with `value` -- what an aborted launch would
+// leave behind.  The next launches must not care (tests/test_gpu_attn.py).
+LD_API int ld_attn_queue_poke(int32_t set, uint32_t value, void* stream) {
+  LD_REQUIRE(set < Q64_QSETS, "ld_attn_queue_poke: set %d of %d", (int)set, Q64_QSETS);
+  hipLaunchKernelGGL(ld_q64_queue_fill_kernel, dim3(Q64_QSETS), dim3(64), 0, (hipStream_t)stream, (int)set, (unsigned)value);
+  return ld_check_launch("ld_attn_queue_poke");
 }

@@ -22,6 +22,12 @@ int ld_check_launch(const char* what);
 struct LdSmemCache { size_t bytes[16]; };     // indexed by device ordinal; devices >= 16 are never cached
 int ld_ensure_dyn_smem(const void* kernel, size_t bytes, LdSmemCache* cache);
 
+// Tuning knobs (LD_* environment variables) are read ONCE per process -- getenv races with setenv / os.environ writes from other
+// host threads -- unless LD_TUNING=1 was set when the library first looked: then every call re-reads them, so that one process
+// (tests, tools/*_ab.py) can alternate two forms.  `cache` is a static int initialised to LD_KNOB_UNSET at the call site.
+#define LD_KNOB_UNSET (-0x7fffffff)
+int ld_knob(const char* name, int dflt, int* cache);
+
 #define LD_REQUIRE(cond, ...)                                  \
   do {                                                         \
     if (!(cond)) return ld_set_error(LD_ERR_INVALID, __VA_ARGS__); \

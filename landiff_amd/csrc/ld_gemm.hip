@@ -1631,9 +1631,9 @@ int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
   }
   dim3 grid((unsigned)((persist && ntiles > ncu) ? ncu : ntiles)), block(512);
   const int epi = pick_epilogue(p);
-  // LD_GEMM_SP=1 (read per call: tools/gemm_ab.py times both loops alternately in one process): the software-pipelined loop
-  const char* spe = getenv("LD_GEMM_SP");
-  if (!conv && spe && atoi(spe) == 1 && (p.K / BK) % 2 == 0 && p.K / BK >= 4) {
+  // LD_GEMM_SP=1: the software-pipelined loop (with LD_TUNING=1 re-read per call: tools/gemm_ab.py times both loops alternately)
+  static int k_sp = LD_KNOB_UNSET;
+  if (!conv && ld_knob("LD_GEMM_SP", 0, &k_sp) == 1 && (p.K / BK) % 2 == 0 && p.K / BK >= 4) {
     switch (epi) {
       case EPI_QKV: return launch_kernel<ld_gemm_sp_kernel<EPI_QKV>>("ld_gemm_qkv_heads(sp)", grid, block, SMEM, stream, p);
       case EPI_BIAS: return launch_kernel<ld_gemm_sp_kernel<EPI_BIAS>>("ld_gemm_sp", grid, block, SMEM, stream, p);
@@ -1683,7 +1683,8 @@ constexpr long CONV_8P_MAX_BYTES = 0x7fffffffL;
 constexpr long CONV_MAX_BYTES = 1L << 33;
 
 enum { ROUTE_128_2STAGE = 0, ROUTE_256_2STAGE = 1, ROUTE_256_8PHASE = 2, ROUTE_256_W4R = 3 };
-int g_last_route = -1;          // what launch() picked last (ld_conv_route's dry run reads it)
+thread_local int g_last_route = -1;   // what launch() picked last ON THIS HOST THREAD (ld_conv_route's dry run reads it; the
+                                      // pipeline runs launches from a helper thread too)
 
 int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = false) {
   // LD_GEMM_TILE (tuning knob): 1 = 128x128 / 4 waves, 3 = 256x256 / 8 waves (both 2-stage, barrier-drained, 16x16x32 MFMAs

@@ -341,26 +341,26 @@ class LLMRunner:
         self._prefill(feats)
         self.pos.fill_(S_last)
         self._sample_and_advance(guided, guidance_scale, temperature, generator)
-        self._pos_host = S_last + 1
-        if self._mode == "fused":
-            self.fused_ctl.zero_()
-        elif self._mode == "chained":
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-                self._chain_ev = torch.cuda.Event()
-            self.chain_ctl.zero_()
-            self._chain_epoch = 0
-            self._side.wait_stream(torch.cuda.current_stream(dev))      # the prefill's KV cache and the zeroed counters
-        note_position(S_last + 1)
-        if logits_log is not None:
-            logits_log.append(self.cfg_logits.clone())
-        steps = full_len - (S_last + 1) - 1
-        debug = teacher_fed is not None or logits_log is not None
-        graph = None
-        if use_graph and not debug and steps > 4:
-            graph = self._capture(guided, guidance_scale, temperature, generator)
-        t_enq = time.perf_counter()
-        try:
+        try:                               # from here on the host-side position is live: the finally below always retires it
+            self._pos_host = S_last + 1
+            if self._mode == "fused":
+                self.fused_ctl.zero_()
+            elif self._mode == "chained":
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                    self._chain_ev = torch.cuda.Event()
+                self.chain_ctl.zero_()
+                self._chain_epoch = 0
+                self._side.wait_stream(torch.cuda.current_stream(dev))      # the prefill's KV cache and the zeroed counters
+            note_position(S_last + 1)
+            if logits_log is not None:
+                logits_log.append(self.cfg_logits.clone())
+            steps = full_len - (S_last + 1) - 1
+            debug = teacher_fed is not None or logits_log is not None
+            graph = None
+            if use_graph and not debug and steps > 4:
+                graph = self._capture(guided, guidance_scale, temperature, generator)
+            t_enq = time.perf_counter()
             for it in range(steps):
                 if teacher_fed is not None:
                     self.token.copy_(teacher_fed[it].reshape(1))

@@ -201,6 +201,17 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tens
     return out
 
 
+def reset() -> None:
+    """ld_reset on the current stream: forget the stream -> counter-set assignments of the dynamic attention launch on the current
+    device and zero the sets.  Only when no attention launch is in flight on another stream (after a device synchronise)."""
+    check(_lib.load().ld_reset(_stream()), "ld_reset")
+
+
+def attn_queue_poke(value: int, set_index: int = -1) -> None:
+    """Test hook (ld_attn_queue_poke): leave `value` in the attention work-queue counters, as an aborted launch would."""
+    check(_lib.load().ld_attn_queue_poke(set_index, value, _stream()), "ld_attn_queue_poke")
+
+
 # ------------------------------------------------------------------------------------------------
 # small-batch / LLM kernels
 # ------------------------------------------------------------------------------------------------

@@ -363,12 +363,89 @@ def rank_core_slice(local_rank: int, local_world: int, cores: list | None = None
     return list(cores[local_rank * per:(local_rank + 1) * per])
 
 
+def _parse_cpulist(text: str) -> list:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_nodes(sysfs: str = "/sys") -> tuple:
+    """(numa node of every visible AMD GPU in device order, {node: [cpus]}) read from sysfs WITHOUT touching HIP: the cards whose
+    PCI vendor is 0x1002 and that expose a compute hwmon, sorted by PCI address (the order HIP enumerates them in on one node),
+    filtered by a plain integer list in HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  A node of -1 or an
+    unreadable file gives None for that GPU."""
+    import glob
+    cards = []
+    for dev in glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*/device")):
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                continue
+            pci = os.path.basename(os.path.realpath(dev))
+            try:
+                node = int(open(os.path.join(dev, "numa_node")).read())
+            except (OSError, ValueError):
+                node = -1
+            cards.append((pci, node if node >= 0 else None))
+        except OSError:
+            continue
+    cards = [n for _, n in sorted(set(cards))]
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                cards = [cards[int(i)] for i in v.split(",")]
+            except (ValueError, IndexError):
+                cards = []                      # UUID lists etc.: no claim about the order
+            break
+    cpus = {}
+    for n in {c for c in cards if c is not None}:
+        try:
+            cpus[n] = _parse_cpulist(open(os.path.join(sysfs, f"devices/system/node/node{n}/cpulist")).read())
+        except OSError:
+            cpus[n] = []
+    return cards, cpus
+
+
+def rank_core_plan(local_world: int, cores: list, gpu_nodes: list | None = None, node_cpus: dict | None = None) -> list:
+    """Core slice of EVERY local rank (a pure function of its arguments, so all ranks compute the same plan).  When the NUMA node
+    of every rank's GPU is known and each node has at least as many allowed cores as ranks on it, a rank gets a contiguous share
+    of the allowed cores of ITS GPU's node (ranks that share a node split it in rank order): launches, the RCCL proxy and the
+    pinned prompt buffers stay on the socket the GPU hangs off.  Otherwise the plain cut of the cpuset into `local_world`
+    contiguous slices (rank_core_slice)."""
+    plain = [rank_core_slice(r, local_world, cores) for r in range(local_world)]
+    if not gpu_nodes or len(gpu_nodes) < local_world or any(n is None for n in gpu_nodes[:local_world]) or not node_cpus:
+        return plain
+    allowed = set(cores)
+    by_node = {}
+    for r in range(local_world):
+        by_node.setdefault(gpu_nodes[r], []).append(r)
+    plan = [None] * local_world
+    for node, ranks in by_node.items():
+        mine = [c for c in sorted(node_cpus.get(node, [])) if c in allowed]
+        if len(mine) < len(ranks):
+            return plain
+        per = len(mine) // len(ranks)
+        for i, r in enumerate(ranks):
+            plan[r] = mine[i * per:(i + 1) * per]
+    return plan
+
+
 def pin_rank_cores(local_rank: int, local_world: int) -> list:
-    """Applies rank_core_slice to this process (all threads created afterwards inherit it) and sizes torch's intra-op pool to
-    it.  Returns the slice.  LD_NO_PIN=1 leaves the affinity alone."""
+    """Applies this rank's slice of rank_core_plan (the cores of its GPU's NUMA node when sysfs exposes it, else the plain cut) to
+    this process -- call it BEFORE the first HIP call: all threads created afterwards inherit it -- and sizes torch's intra-op pool
+    to it.  Returns the slice.  LD_NO_PIN=1 leaves the affinity alone."""
     if os.environ.get("LD_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
         return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
-    mine = rank_core_slice(local_rank, local_world)
+    cores = sorted(os.sched_getaffinity(0))
+    try:
+        nodes, cpus = gpu_numa_nodes()
+    except Exception:                            # sysfs layout surprises must never stop a run
+        nodes, cpus = None, None
+    mine = rank_core_plan(local_world, cores, nodes, cpus)[local_rank] if local_world > 1 else cores
     if mine:
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, min(len(mine), torch.get_num_threads())))

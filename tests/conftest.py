@@ -5,6 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("LANDIFF_SKIP_INIT", "1")      # importing `landiff` would otherwise look for / download the released checkpoints
+os.environ.setdefault("LD_TUNING", "1")              # the library re-reads its LD_* knobs on every call (tests alternate kernel forms in one process)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/landiff_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.ld_version() == _lib.ABI_VERSION == 5
+    assert lib.ld_version() == _lib.ABI_VERSION == int(re.search(r"#define LD_ABI_VERSION (\d+)", hdr).group(1))
     assert ctypes.sizeof(_lib.Epilogue) == 120          # layout of ld_epilogue_t
 
 
@@ -236,18 +236,60 @@ def test_sat_checkpoint_layout_round_trip(tmp_path):
     assert set(out["vae"]) == {"decoder.conv_in.conv.weight"}
 
 
-def test_bench_refuses_a_gpu_count_that_is_not_the_world_size():
-    """bench.py --gpus N must equal WORLD_SIZE (one process per GPU under torch.distributed.run): a mismatch would report a
-    wrong n_gpus, so it stops before touching any device."""
+def test_bench_starts_its_own_ranks_or_refuses_a_mismatched_launcher():
+    """`python bench.py --gpus N` without a launcher starts N ranks as child processes through torch.distributed.run (before any
+    GPU call; here only the command is shown: LD_BENCH_DRY_SPAWN=1).  Under a launcher, --gpus must equal WORLD_SIZE: a mismatch
+    would report a wrong n_gpus, so it stops before touching any device."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LD_BENCH_FORCE_DIST")}
+    env["LD_BENCH_DRY_SPAWN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
-    env["WORLD_SIZE"] = "8"
+    assert r.returncode == 0, r.stderr[-2000:]
+    msg = r.stderr
+    assert "starting 8 rank(s)" in msg and "torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1" in msg
+    assert msg.rstrip().endswith("bench.py --gpus 8 --steps 2 --warmup 1")
+    env.update(WORLD_SIZE="8", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=8" in (r.stderr + r.stdout)
+
+
+def test_rank_core_plan_prefers_the_gpus_numa_node():
+    """rank_core_plan: ranks get cores of their GPU's NUMA node (ranks sharing a node split it), inside the cpuset; any missing
+    piece of information gives the plain contiguous cut for every rank.  gpu_numa_nodes reads a sysfs tree without HIP."""
+    from landiff_amd.pipeline import gpu_numa_nodes, rank_core_plan, rank_core_slice
+    cores = list(range(64))
+    node_cpus = {0: list(range(0, 32)), 1: list(range(32, 64))}
+    plan = rank_core_plan(4, cores, [1, 1, 0, 0], node_cpus)
+    assert plan == [list(range(32, 48)), list(range(48, 64)), list(range(0, 16)), list(range(16, 32))]
+    plain = [rank_core_slice(r, 4, cores) for r in range(4)]
+    assert rank_core_plan(4, cores, [1, None, 0, 0], node_cpus) == plain          # one GPU without a node
+    assert rank_core_plan(4, cores, [0, 1], node_cpus) == plain                   # fewer GPUs known than ranks
+    assert rank_core_plan(4, cores, None, None) == plain
+    assert rank_core_plan(4, list(range(33)), [1, 1, 1, 0], node_cpus) == [rank_core_slice(r, 4, list(range(33))) for r in range(4)]  # node 1: 1 allowed core, 3 ranks
+    flat = [c for sl in plan for c in sl]
+    assert len(flat) == len(set(flat)) == 64
+
+
+def test_gpu_numa_nodes_reads_sysfs_without_hip(tmp_path, monkeypatch):
+    from landiff_amd.pipeline import gpu_numa_nodes
+    for i, (pci, vendor, node) in enumerate([("0000:05:00.0", "0x1002", 0), ("0000:85:00.0", "0x1002", 1), ("0000:01:00.0", "0x1a03", -1)]):
+        real = tmp_path / "devices" / "pci" / pci
+        real.mkdir(parents=True)
+        (real / "vendor").write_text(vendor + "\n"); (real / "numa_node").write_text(f"{node}\n")
+        card = tmp_path / "class" / "drm" / f"card{i}"
+        card.mkdir(parents=True)
+        os.symlink(real, card / "device")
+    for n, cl in ((0, "0-3,8-9"), (1, "4-7")):
+        d = tmp_path / "devices" / "system" / "node" / f"node{n}"
+        d.mkdir(parents=True); (d / "cpulist").write_text(cl + "\n")
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    nodes, cpus = gpu_numa_nodes(str(tmp_path))
+    assert nodes == [0, 1] and cpus == {0: [0, 1, 2, 3, 8, 9], 1: [4, 5, 6, 7]}
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert gpu_numa_nodes(str(tmp_path))[0] == [1]
 
 
 def test_save_video_tensor_fallback_writes_playable_avi(tmp_path):

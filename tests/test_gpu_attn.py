@@ -151,9 +151,10 @@ def _qkv(cuda, B, H, N, seed):
 
 @pytest.mark.parametrize("B,H,N", [(2, 30, 17776), (1, 40, 13100)])
 def test_attn_dynamic_queue_equals_round_robin_dispatch(cuda, monkeypatch, B, H, N):
-    """Grids of >= four rounds take the dynamic form by default; LD_ATTN_DYN=0 (read per call) is the hardware's own dispatch of
-    one workgroup per query block.  Same per-block code: identical bits.  The queue counters are static device memory in 64
-    sets, re-zeroed by the last workgroup to leave: 70 launches in a row, and launches on two streams at once, stay identical."""
+    """Grids of >= four rounds take the dynamic form by default; LD_ATTN_DYN=0 (re-read per call under LD_TUNING=1, conftest) is the
+    hardware's own dispatch of one workgroup per query block.  Same per-block code: identical bits.  The queue counters are static
+    device memory in 64 sets, one per (device, stream), zeroed on the stream before each launch: 70 launches in a row, and launches
+    on two streams at once, stay identical."""
     from landiff_amd import ops
     q, k, vt = _qkv(cuda, B, H, N, seed=N)
     monkeypatch.setenv("LD_ATTN_DYN", "0")
@@ -183,3 +184,62 @@ def test_attn_dynamic_queue_equals_round_robin_dispatch(cuda, monkeypatch, B, H,
             ops.attn_fwd(q2, k2, vt2, o2[i], N, N, 0.125)
     torch.cuda.synchronize()
     assert all(torch.equal(o, ref) for o in o1) and all(torch.equal(o, ref2) for o in o2)
+
+
+def test_attn_dynamic_queue_survives_poisoned_counters_and_stream_exhaustion(cuda):
+    """The one piece of library state (include/landiff_hip.h): (i) counters left dirty by a launch that died mid-flight -- simulated
+    with ld_attn_queue_poke -- do not reach the next launch (the set is zeroed on the launch stream first); (ii) ld_reset puts the
+    sets and the stream assignments back; (iii) the 65th stream of a device that launches attention gets no set and takes the
+    static launch of the same body; (iv) so does a launch captured into a graph.  Every output bit-identical."""
+    from landiff_amd import ops
+    B, H, N = 2, 30, 17776
+    q, k, vt = _qkv(cuda, B, H, N, seed=5)
+    torch.cuda.synchronize()
+    ops.reset()
+    ref = torch.zeros(B, N, H * 64, device=cuda, dtype=torch.bfloat16)
+    ops.attn_fwd(q, k, vt, ref, N, N, 0.125)
+    assert _last_kernel() == "ld_attn_q64_dyn_kernel"
+    out = torch.zeros_like(ref)
+    for value in (0xFFFFFFFF, 7, 1 << 20):                       # exhausted / partially consumed / far past the end
+        ops.attn_queue_poke(value)
+        out.zero_()
+        ops.attn_fwd(q, k, vt, out, N, N, 0.125)
+        assert _last_kernel() == "ld_attn_q64_dyn_kernel"
+        assert torch.equal(out, ref), hex(value)
+    ops.attn_queue_poke(0xFFFFFFFF)
+    torch.cuda.synchronize()
+    ops.reset()
+    out.zero_()
+    ops.attn_fwd(q, k, vt, out, N, N, 0.125)
+    assert torch.equal(out, ref)
+    # 70 distinct streams: the first 63 new ones (the current stream holds a set since the reset) run the dynamic form, the rest the static one
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(70)]
+    outs = [torch.zeros_like(ref) for _ in range(4)]
+    names = []
+    for i, s in enumerate(streams):
+        with torch.cuda.stream(s):
+            o = outs[i % 4]
+            if i >= 4:
+                s.wait_stream(streams[i - 4])                    # the buffer's previous user
+            ops.attn_fwd(q, k, vt, o, N, N, 0.125)
+            names.append(_last_kernel())
+        if i % 4 == 3:
+            torch.cuda.synchronize()
+            assert all(torch.equal(o, ref) for o in outs), i
+            for o in outs:
+                o.zero_()
+    torch.cuda.synchronize()
+    assert names.count("ld_attn_q64_dyn_kernel") == 63 and names[63:] == ["ld_attn_q64_kernel"] * 7, names
+    ops.reset()
+    # captured launch: static form, replay equals eager
+    g = torch.cuda.CUDAGraph()
+    out.zero_()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            ops.attn_fwd(q, k, vt, out, N, N, 0.125)
+            assert _last_kernel() == "ld_attn_q64_kernel"
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)

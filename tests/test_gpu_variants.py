@@ -243,27 +243,38 @@ def test_gemv_streaming_loop_variant(cuda):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_bench_rccl_path_single_rank(cuda):
-    """bench.py launched the way the driver launches the N-GPU runs (torch.distributed.run, one rank per GPU), with one
-    rank and LD_BENCH_FORCE_DIST=1: RCCL init, barrier, all_gather of the uint8 frames, all_reduce(MAX) of the time."""
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_rccl_path_single_rank(cuda, launcher):
+    """bench.py launched the way the driver launches the N-GPU runs (torch.distributed.run, one rank per GPU) and the plain way
+    (`python bench.py --gpus N`, which starts its own ranks as child processes), with one rank and LD_BENCH_FORCE_DIST=1: RCCL
+    init, barrier, all_gather of the uint8 frames, all_reduce(MAX) of the time."""
     import json
     e = dict(os.environ); e["LD_BENCH_FORCE_DIST"] = "1"; e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--tiny",
-           "--no-cpu-baseline"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LD_BENCH_DRY_SPAWN"):
+        e.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--tiny", "--no-cpu-baseline"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29517"] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    if launcher == "self":
+        assert "starting 1 rank(s)" in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["unit"] == "frames/s"
     # the line's contract: the driver's keys, the roofline object of the dominant kernel, the calibration of the box, per-rank reports
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "roofline_stages", "calibration", "per_rank"):
+              "dtype", "data", "config", "roofline", "roofline_stages", "calibration", "per_rank", "n_ranks_seen"):
         assert k in res, k
+    assert res["n_ranks_seen"] == 1                      # RCCL's own count of the job
     assert res["scaling"] == "weak" and res["higher_is_better"] is True and res["vs_baseline"] is None and res["data"] == "synthetic"
     assert "workload" in res["config"] and "model" not in res["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms"):
         assert k in res["roofline"], k
+    assert res["roofline"]["achieved"] > 0 and res["roofline"]["launches"] > 0      # (tiny config: no launch runs alone -> all launches, labelled)
     assert res["roofline"]["bound"] == "mfma" and res["roofline"]["frac"] == pytest.approx(res["roofline"]["achieved"] / res["roofline"]["peak"], abs=1e-3)
     assert res["calibration"]["mfma_tflops"] > 100 and res["calibration"]["hbm_gbs"] > 500
     assert len(res["per_rank"]["frames_per_s"]) == 1
