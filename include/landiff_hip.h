@@ -222,7 +222,10 @@ int ld_llm_rope_append(const void* qkv, const float* cos_t, const float* sin_t, 
  * m == 1 with nsplit > 1 uses the key-split path (workspace: B*H*(nsplit*130 + 1) 4-byte words, caller-owned; the last B*H
  * words are arrival counters that must be ZERO before the first call -- the launch leaves them zero: the last split of a
  * (batch row, head) to arrive merges the partial results, no second launch; p kept fp32); there
- * qkv_fused ([B][3][H][128], q may be NULL) makes the kernel do apply_rope and the KV append of the new token itself. */
+ * qkv_fused ([B][3][H][128], q may be NULL) makes the kernel do apply_rope and the KV append of the new token itself.
+ * nsplit is the MAXIMUM number of key splits (it sizes the workspace and must keep Lmax / nsplit <= 256): a step at context length
+ * L = *pos + 1 uses 1 / 2 / 4 / nsplit of them by a fixed rule of L alone (short contexts are not worth a merge; one split writes
+ * the output directly), evaluated on the device, so every way of issuing the step gives the same bits. */
 int ld_llm_kv_attn(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
                    int64_t B, int64_t m, int64_t H, int64_t Lmax, float* workspace, int64_t nsplit,
                    const void* qkv_fused, const float* cos_t, const float* sin_t, void* stream);

@@ -13,6 +13,7 @@
 // All per-step scalars (position, token) live in device memory so the whole step is graph-capturable.
 #include "ld_common.h"
 #include "ld_llm_dev.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include "../../include/landiff_hip.h"
 
@@ -628,20 +629,26 @@ template <bool CHAIN>
 __global__ __launch_bounds__(256, CHAIN ? 2 : 1) void ld_kv_attn_split_kernel(const bf16_t* q, const bf16_t* qkv, const float* cos_t,
                                                                const float* sin_t, bf16_t* kc, bf16_t* vc,
                                                                const int* pos_ptr, int pos_value, float* ws, unsigned* counters,
-                                                               bf16_t* out, int B, int H, int Lmax, int nsplit, ChainSync cs) {
-  extern __shared__ float sc[];       // [chunk] (unused since the scores live in registers) + reductions
+                                                               bf16_t* out, int B, int H, int Lmax, int nsplit, KvSplitRule rule,
+                                                               ChainSync cs) {
+  __shared__ float red[8 + 4 * 128];
   __shared__ int is_last;
   const int D = 128;
   const int bh = blockIdx.x, sp = blockIdx.y;
   const int b = bh / H, h = bh - b * H;
   const int L = (pos_value >= 0 ? pos_value : *pos_ptr) + 1;
-  const int chunk = (L + nsplit - 1) / nsplit;
+  const int ns = kv_eff_splits(L, nsplit, rule);       // splits in use at this context length; partial results keep the [bh][nsplit] layout
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (sp >= ns) {                                      // a split this step does not use
+    if (CHAIN) { chain_wait(cs, tid); chain_arrive(cs, tid, blockIdx.y * gridDim.x + blockIdx.x); }
+    return;
+  }
+  const int chunk = (L + ns - 1) / ns;
   const int k_begin = sp * chunk, k_end = min(L, k_begin + chunk);
   const int n = max(0, k_end - k_begin);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 15, kq = lane >> 4;
   float* out_ws = ws + ((long)bh * nsplit + sp) * (D + 2);
-  float* red = sc + ((Lmax + nsplit - 1) / nsplit + 16);
+  bf16_t* direct = (ns == 1 && !CHAIN) ? out + (long)bh * D : nullptr;
   KvRows rows;
   if (CHAIN) {
     if (n > 0) kv_rows_request(rows, kc, vc, (long)b * Lmax + k_begin, H, h, n, wave, kq, sub);
@@ -677,21 +684,25 @@ __global__ __launch_bounds__(256, CHAIN ? 2 : 1) void ld_kv_attn_split_kernel(co
     }
     if (!CHAIN) kv_rows_request(rows, kc, vc, (long)b * Lmax + k_begin, H, h, n, wave, kq, sub);
     kv_attn_split_core(rows, a_q, a_k, a_v, cs_, sn, qkv != nullptr, kc, vc, (long)b * Lmax + pos, H, h, pos - k_begin, n, true,
-                       out_ws, red, red + 8, tid, lane, wave, [](float* p, float v) { st_agent(p, v); });
+                       out_ws, red, red + 8, tid, lane, wave, [](float* p, float v) { st_agent(p, v); }, direct);
   }
-  // Hand-off in the write-through form (cdna_hip_programming.md section 6 Guideline 16, recipe R1): the partial results were
-  // stored sc1 (st_agent: they leave this XCD's L2), EVERY storing wave drains vmcnt, the workgroup meets, ONE lane arrives
-  // with a relaxed agent-scope add; the last arriver reads the partials with sc1 loads (ld_agent: L1 bypassed), which stand in
-  // for the acquire because the producers stored sc1.  A release/acquire pair on the counter instead would put a
-  // buffer_wbl2 + buffer_inv (~3.5 us, MI355X_MICROARCH.md) into each of the 24 x 1244 launches of a decode.
+  if (direct) return;                                  // one split: the output row is written, nothing to merge, no counter traffic
+  // Hand-off in the write-through form (cdna_hip_programming.md section 6 Guideline 16, recipe R1; the second valid form of
+  // MI355X_MICROARCH.md "Valid forms besides R1/R2": {sc1 stores and loads both sides}): the partial results were stored sc1
+  // (st_agent: they leave this XCD's L2), EVERY storing wave drains vmcnt, the workgroup meets, ONE lane arrives with a relaxed
+  // agent-scope add; the last arriver reads the partials with sc1 loads (ld_agent: L1 bypassed), which stand in for the acquire
+  // because the producers stored sc1.  This relies on the ISA-level behaviour of sc1 accesses on gfx950 that the guide documents,
+  // not on the HIP memory model (a relaxed counter orders nothing there); tests/test_gpu_llm_longctx.py and the bit-identity tests
+  // of the decode forms are its check.  A release/acquire pair on the counter instead would put a buffer_wbl2 + buffer_inv
+  // (~3.5 us, MI355X_MICROARCH.md) into each of the 24 x 1244 launches of a decode.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's part of the partial result is at the coherence point
   __syncthreads();
   if (tid == 0)
-    is_last = __hip_atomic_fetch_add(counters + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
+    is_last = __hip_atomic_fetch_add(counters + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ns - 1);
   __syncthreads();
   if (is_last) {
     if (tid < D) {
-      const float r = kv_attn_combine_core(ws + (long)bh * nsplit * (D + 2), nsplit, tid, [](const float* p) { return ld_agent(p); });
+      const float r = kv_attn_combine_core(ws + (long)bh * nsplit * (D + 2), ns, tid, [](const float* p) { return ld_agent(p); });
       if (CHAIN) __hip_atomic_store(out + (long)bh * D + tid, f2bf(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else out[(long)bh * D + tid] = f2bf(r);
     }
@@ -924,6 +935,18 @@ int launch_gemv_b(const GemvParams& p, hipStream_t st) {
 
 }  // namespace
 
+KvSplitRule ld_kv_split_rule() {
+  static const KvSplitRule rule = [] {
+    KvSplitRule r{KV_SPLIT_T1, KV_SPLIT_T2, KV_SPLIT_T4};
+    if (const char* e = getenv("LD_KV_SPLIT_T")) {
+      int a = 0, b = 0, c = 0;
+      if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) r = KvSplitRule{a, b, c};
+    }
+    return r;
+  }();
+  return rule;
+}
+
 LD_API int ld_gemv(const void* x, int64_t ldx, int32_t x_f32, const void* W, const void* W2, int32_t w_f32,
                    const void* bias, const void* resid, int64_t ldr, void* out, int64_t ldo, int32_t out_f32,
                    int64_t B, int64_t N, int64_t K, int32_t in_act, int32_t act, const float* norm_w, float norm_eps,
@@ -1001,12 +1024,12 @@ static int kv_attn_impl(const void* q, const void* k_cache, const void* v_cache,
     LD_REQUIRE(!qkv_fused || (cos_t && sin_t), "ld_llm_kv_attn: fused RoPE needs the cos/sin tables");
     LD_REQUIRE((Lmax + nsplit - 1) / nsplit <= 16 * KV_MAXIT, "ld_llm_kv_attn: Lmax=%ld needs nsplit >= %ld (<= 256 keys per split)",
                (long)Lmax, (long)((Lmax + 255) / 256));
-    const size_t chunk = (size_t)((Lmax + nsplit - 1) / nsplit + 16);
-    const size_t smem = (chunk + 8 + 4 * 128) * sizeof(float);
-    hipLaunchKernelGGL(ld_kv_attn_split_kernel<false>, dim3((unsigned)(B * H), (unsigned)nsplit), dim3(256), smem, st,
+    // the position is known on the host: do not even launch the splits this step leaves unused
+    const int ny = pos_value >= 0 ? kv_eff_splits(pos_value + 1, (int)nsplit, ld_kv_split_rule()) : (int)nsplit;
+    hipLaunchKernelGGL(ld_kv_attn_split_kernel<false>, dim3((unsigned)(B * H), (unsigned)ny), dim3(256), 0, st,
                        (const bf16_t*)q, (const bf16_t*)qkv_fused, cos_t, sin_t, (bf16_t*)k_cache, (bf16_t*)v_cache,
                        (const int*)pos, (int)pos_value, workspace, (unsigned*)(workspace + B * H * nsplit * 130), (bf16_t*)out, (int)B,
-                       (int)H, (int)Lmax, (int)nsplit, ChainSync{});
+                       (int)H, (int)Lmax, (int)nsplit, ld_kv_split_rule(), ChainSync{});
     return ld_check_launch("ld_llm_kv_attn(split)");
   }
   LD_REQUIRE(q && !qkv_fused, "ld_llm_kv_attn: the fused RoPE/append form exists only for the decode split path");
@@ -1114,18 +1137,16 @@ LD_API int ld_llm_decode_blocks_chained(const ld_llm_layer* layers, int64_t n_la
     prev_grid = grid; ++slot;
     return r;
   };
-  const size_t chunk = (size_t)((Lmax + nsplit - 1) / nsplit + 16);
-  const size_t smem = (chunk + 8 + 4 * 128) * sizeof(float);
   for (int64_t i = 0; i < n_layers && rc == 0; ++i) {
     const ld_llm_layer& w = layers[i];
     LD_REQUIRE(w.wqkv && w.wo && w.w1 && w.w3 && w.w2 && w.n0 && w.n1 && w.k_cache && w.v_cache,
                "ld_llm_decode_blocks_chained: layer %ld has a null pointer", (long)i);
     rc = gemv(x, hidden, w.wqkv, nullptr, nullptr, qkv, 3 * hidden, 3 * hidden, hidden, 0, w.n0);
     if (rc) break;
-    hipLaunchKernelGGL(ld_kv_attn_split_kernel<true>, dim3((unsigned)(B * heads), (unsigned)nsplit), dim3(256), smem, st[slot & 1],
+    hipLaunchKernelGGL(ld_kv_attn_split_kernel<true>, dim3((unsigned)(B * heads), (unsigned)nsplit), dim3(256), 0, st[slot & 1],
                        (const bf16_t*)nullptr, (const bf16_t*)qkv, cos_t, sin_t, (bf16_t*)w.k_cache, (bf16_t*)w.v_cache, (const int*)nullptr,
                        (int)pos_value, attn_ws, (unsigned*)(attn_ws + B * heads * nsplit * 130), (bf16_t*)att, (int)B, (int)heads,
-                       (int)Lmax, (int)nsplit, sync());
+                       (int)Lmax, (int)nsplit, ld_kv_split_rule(), sync());
     rc = ld_check_launch("ld_llm_kv_attn(chained)");
     if (rc) break;
     prev_grid = (int)(B * heads * nsplit); ++slot;

@@ -49,6 +49,21 @@ __device__ __forceinline__ float chunks_sumsq(const u32x4_t (&x)[J]) {
 constexpr int KV_MAXIT = 16;     // trips of 16 keys per 256 threads: a split covers at most 256 keys
 struct KvRows { u32x4_t k[KV_MAXIT], v[KV_MAXIT]; };
 
+// How many of the launch's `nsplit_max` key splits a decode step at context length L really uses: a short context is not worth a
+// merge (one split: the workgroup writes the attention output itself), a medium one not worth eight arrivals.  A pure function of
+// L, evaluated on the device by every form of the decode step (per-operation launches, the chained and the persistent form, a
+// captured graph), so that all of them keep producing the same bits; workgroups of unused splits leave at once.
+// t1 / t2 / t4: longest context served by 1 / 2 / 4 splits (LD_KV_SPLIT_T=t1,t2,t4; LD_KV_SPLIT_T=0,0,0: always nsplit_max).
+struct KvSplitRule { int t1, t2, t4; };
+constexpr int KV_SPLIT_T1 = 128, KV_SPLIT_T2 = 384, KV_SPLIT_T4 = 768;      // defaults: tools/kv_attn_sweep.py
+__host__ __device__ inline int kv_eff_splits(int L, int nsplit_max, KvSplitRule r) {
+  int ns = L <= r.t1 ? 1 : L <= r.t2 ? 2 : L <= r.t4 ? 4 : nsplit_max;
+  if (ns > nsplit_max) ns = nsplit_max;
+  while ((L + ns - 1) / ns > 16 * KV_MAXIT && ns < nsplit_max) ns = 2 * ns < nsplit_max ? 2 * ns : nsplit_max;
+  return ns;
+}
+KvSplitRule ld_kv_split_rule();      // ld_llm.hip (environment knob, read once)
+
 // rows k_begin .. k_begin + n of (b, h) in caches laid out [B][Lmax][H][128]; row0 = b * Lmax + k_begin
 __device__ __forceinline__ void kv_rows_request(KvRows& r, const bf16_t* kc, const bf16_t* vc, long row0, int H, int h, int n,
                                                 int wave, int kq, int sub) {
@@ -65,6 +80,7 @@ __device__ __forceinline__ void kv_rows_request(KvRows& r, const bf16_t* kc, con
   }
 }
 
+// direct_out != nullptr: this split is the whole context -- the normalised bf16 output row is written there, no partial result.
 // Store: functor (float* p, float v) -- plain or agent-coherent.  red: 8 floats, part: 4 * 128 floats of LDS owned by these
 // 256 threads; contains three workgroup barriers (every thread of the workgroup must get here, active or not).
 // rope: a_q / a_k / a_v are the new token's raw chunks, rotated here (apply_rope, pos_emb.py:16-46); the split that holds
@@ -73,7 +89,7 @@ template <class Store>
 __device__ __forceinline__ void kv_attn_split_core(KvRows& r, u32x4_t a_q, u32x4_t a_k, u32x4_t a_v, const float (&cs)[4],
                                                    const float (&sn)[4], bool rope, bf16_t* kc, bf16_t* vc, long cache_row,
                                                    int H, int h, int pk, int n, bool active, float* out_ws, float* red,
-                                                   float* part, int t, int lane, int wave, Store store) {
+                                                   float* part, int t, int lane, int wave, Store store, bf16_t* direct_out = nullptr) {
   constexpr int D = 128;
   const int sub = lane & 15, kq = lane >> 4;
   float qreg[8];
@@ -150,8 +166,12 @@ __device__ __forceinline__ void kv_attn_split_core(KvRows& r, u32x4_t a_q, u32x4
   if (lane == 0) red[4 + wave] = lsum;
   __syncthreads();
   if (active) {
-    if (t < D) store(out_ws + 2 + t, part[t] + part[D + t] + part[2 * D + t] + part[3 * D + t]);
-    if (t == 0) { store(out_ws, mx); store(out_ws + 1, red[4] + red[5] + red[6] + red[7]); }
+    if (direct_out) {            // the only split of its (batch row, head): what the merge of one partial result would give, o / l
+      if (t < D) direct_out[t] = f2bf((part[t] + part[D + t] + part[2 * D + t] + part[3 * D + t]) / (red[4] + red[5] + red[6] + red[7]));
+    } else {
+      if (t < D) store(out_ws + 2 + t, part[t] + part[D + t] + part[2 * D + t] + part[3 * D + t]);
+      if (t == 0) { store(out_ws, mx); store(out_ws + 1, red[4] + red[5] + red[6] + red[7]); }
+    }
   }
 }
 

@@ -43,6 +43,7 @@ struct FusedParams {
   bf16_t *x, *qkv, *att, *gate; float* ws;
   const float *cos_t, *sin_t; const int* pos;
   int hidden, heads, mlp, Lmax, nsplit; float rms_eps;
+  KvSplitRule rule;         // splits in use at context length L: kv_eff_splits (ld_llm_dev.h), the same rule as the per-operation launch
   unsigned* ctl;
 };
 
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(NT) void ld_llm_blocks_fused_kernel(FusedParams p) 
 
   // attention work items: (batch row, head, key split); item gs (+ NSG per round)
   const int L = *p.pos + 1, pos = L - 1;
-  const int nsplit = p.nsplit, chunk = (L + nsplit - 1) / nsplit;
-  const int n_items = FB * H * nsplit, rounds = (n_items + NSG - 1) / NSG;
+  const int nsplit = p.nsplit, ns = kv_eff_splits(L, nsplit, p.rule), chunk = (L + ns - 1) / ns;
+  const int n_items = FB * H * ns, rounds = (n_items + NSG - 1) / NSG;      // partial results keep the [bh][nsplit] layout
 
   WB<R_QKV, 1, false> q0, q1;
   WB<R_WO, 1, false> o0, o1;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(NT) void ld_llm_blocks_fused_kernel(FusedParams p) 
   int par = 0;
 
   auto item_geom = [&](int item, int& b, int& h, int& k_begin, int& n) {
-    const int bh = item / nsplit, sp = item - bh * nsplit;
+    const int bh = item / ns, sp = item - bh * ns;
     b = bh / H; h = bh - b * H;
     k_begin = sp * chunk;
     n = max(0, min(L, k_begin + chunk) - k_begin);
@@ -329,7 +330,8 @@ __global__ __launch_bounds__(NT) void ld_llm_blocks_fused_kernel(FusedParams p) 
       float cs[4], sn[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { cs[e] = p.cos_t[pos * 64 + sub * 4 + e]; sn[e] = p.sin_t[pos * 64 + sub * 4 + e]; }
-      float* out_ws = p.ws + (long)(active ? item : 0) * 130;
+      const int item_a = active ? item : 0;
+      float* out_ws = p.ws + ((long)(item_a / ns) * nsplit + (item_a % ns)) * 130;
       kv_attn_split_core(kv, a_q, a_k, a_v, cs, sn, true, (bf16_t*)w.k_cache, (bf16_t*)w.v_cache, (long)b * p.Lmax + pos, H, h,
                          pos - k_begin, n, active, out_ws, att_lds[sg], att_lds[sg] + 8, t, lane, wave,
                          [](float* q, float v) { stc(q, v); });
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(NT) void ld_llm_blocks_fused_kernel(FusedParams p) 
     // ---- combine the key splits: one (batch row, head) per sub-group ----
     for (int bh = gs; bh < FB * H; bh += NSG) {
       if (t < 128) {
-        const float r = kv_attn_combine_core(p.ws + (long)bh * nsplit * 130, nsplit, t, [](const float* q) { return ldc(q); });
+        const float r = kv_attn_combine_core(p.ws + (long)bh * nsplit * 130, ns, t, [](const float* q) { return ldc(q); });
         stc(p.att + (long)bh * 128 + t, f2bf(r));
       }
     }
@@ -438,7 +440,7 @@ LD_API int ld_llm_decode_blocks_fused(const ld_llm_layer* layers_dev, int64_t n_
   p.layers = layers_dev; p.n_layers = (int)n_layers;
   p.x = (bf16_t*)x; p.qkv = (bf16_t*)qkv; p.att = (bf16_t*)att; p.gate = (bf16_t*)gate; p.ws = attn_ws;
   p.cos_t = cos_t; p.sin_t = sin_t; p.pos = (const int*)pos;
-  p.hidden = (int)hidden; p.heads = (int)heads; p.mlp = (int)mlp; p.Lmax = (int)Lmax; p.nsplit = (int)nsplit; p.rms_eps = rms_eps;
+  p.hidden = (int)hidden; p.heads = (int)heads; p.mlp = (int)mlp; p.Lmax = (int)Lmax; p.nsplit = (int)nsplit; p.rms_eps = rms_eps; p.rule = ld_kv_split_rule();
   p.ctl = (unsigned*)ctl;
   hipLaunchKernelGGL(ld_llm_blocks_fused_kernel<6>, dim3((unsigned)grid), dim3(NT), 0, (hipStream_t)stream, p);
   return ld_check_launch("ld_llm_decode_blocks_fused");

@@ -229,6 +229,7 @@ def test_attn_dynamic_queue_survives_poisoned_counters_and_stream_exhaustion(cud
             assert all(torch.equal(o, ref) for o in outs), i
             for o in outs:
                 o.zero_()
+            torch.cuda.synchronize()                             # (the new streams do not order themselves behind the zero fill)
     torch.cuda.synchronize()
     assert names.count("ld_attn_q64_dyn_kernel") == 63 and names[63:] == ["ld_attn_q64_kernel"] * 7, names
     ops.reset()

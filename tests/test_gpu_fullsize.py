@@ -381,3 +381,51 @@ def test_vae_level0_resblock_full_resolution_vs_oracle(cuda):
     print(f"level-0 VAE resblock 480x720: err {err:.4f} (mean {mean_err:.5f}), bf16-oracle floor {floor:.4f} (mean {mean_floor:.5f})")
     assert err < max(2 * floor, 2e-2), (err, floor)
     assert mean_err < max(2 * mean_floor, 5e-3), (mean_err, mean_floor)
+
+
+def test_vae_full_resolution_two_chunks_vs_oracle(cuda):
+    """The whole 3D-VAE decoder at 480 x 720 on the reference's chunk schedule: 5 latent frames = chunk 0:3 (odd T: replicated
+    first-frame halo, the first-frame rule of both time upsamples and of the SpatialNorm zq gather, 9 frames) + chunk 3:5
+    continued from the kept causal-conv caches (8 frames) -- conv_in, mid blocks, all four levels, conv_out, post-process, uint8 --
+    against the fp32 oracle on the host cores (~110 TFLOP of fp32 conv3d: the slowest test of the suite, a few minutes).
+    No bf16-oracle floor at this size (a bf16 conv3d on the host is several times slower still); measured on MI355X: first chunk
+    max 0.058 / mean 0.0035 of the [0, 1] video range, continued chunk 0.044 / 0.0035, uint8 frames 0.9 grey levels apart on
+    average -- the level of the tiny-size test against the bf16 oracle (tests/test_gpu_stages.py::test_vae_decode: 6e-2 / 4e-3).
+    The bounds below leave ~1.4x of that for a different summation order of the GroupNorm statistics.
+    Reference: landiff/diffusion/vae_modules/cp_enc_dec.py:416-473,605-633,1034-1069, landiff/diffusion/dif_infer.py:245-271."""
+    import time
+    from landiff_amd.config import VAEConfig
+    from landiff_amd.vae import VAEDecoder
+    from landiff_amd.weights import init_state, vae_spec
+    from oracle.vae import VAEDecoderOracle, post_process, to_uint8_frames
+    cfg = VAEConfig()
+    sd = init_state(vae_spec(cfg), 41)
+    g = torch.Generator().manual_seed(8)
+    Tl, h, w = 5, 60, 90
+    latent = torch.randn(1, Tl, cfg.z_channels, h, w, generator=g).to(torch.bfloat16).float()
+    vae = VAEDecoder(sd, cfg, cuda)
+    frames, video = vae.decode(latent.to(cuda), want_float=True)
+    assert tuple(frames.shape) == (17, 480, 720, 3) and frames.dtype == torch.uint8
+    frames, video = frames.cpu(), video.cpu()
+    # streaming at full resolution: decode(0:3, keep) + decode(3:5, continue) are the one-call frames, bit for bit
+    fa = vae.decode(latent[:, :3].to(cuda), stream_keep=True)
+    fb = vae.decode(latent[:, 3:5].to(cuda), stream_continue=True)
+    assert torch.equal(torch.cat([fa, fb], 0).cpu(), frames)
+    del vae, fa, fb
+    torch.cuda.empty_cache()
+    assert torch.equal(frames, to_uint8_frames(video))                      # uint8 = trunc(255 x float video), exactly
+    torch.set_num_threads(min(64, max(torch.get_num_threads(), torch.get_num_threads() * 8)))
+    t0 = time.perf_counter()
+    orc = VAEDecoderOracle(sd, cfg, torch.float32)
+    ref = post_process(orc.decode_latent(latent.permute(0, 2, 1, 3, 4)))[0]  # [3, 17, 480, 720]
+    dt = time.perf_counter() - t0
+    assert ref.shape == video.shape == (3, 17, 480, 720)
+    err = (video - ref).abs()
+    per_chunk = [(err[:, :9].max().item(), err[:, :9].mean().item()), (err[:, 9:].max().item(), err[:, 9:].mean().item())]
+    grey = (frames.float() - to_uint8_frames(ref).float()).abs()
+    print(f"VAE 480x720, 5 latent frames -> 17 frames vs fp32 oracle ({dt:.0f} s of host CPU): first chunk max {per_chunk[0][0]:.4f} "
+          f"mean {per_chunk[0][1]:.5f}, continued chunk max {per_chunk[1][0]:.4f} mean {per_chunk[1][1]:.5f}; uint8 frames differ by "
+          f"{grey.mean().item():.3f} grey levels on average, {int(grey.max().item())} at most; oracle video std {ref.std().item():.3f}")
+    for mx, mean in per_chunk:
+        assert mx < 8e-2 and mean < 5e-3, per_chunk
+    assert grey.mean().item() < 1.5
