@@ -253,6 +253,11 @@ int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, const fl
                           const float* head_w, float* logits, int64_t B, int64_t hidden, int64_t heads, int64_t mlp,
                           int64_t vocab, int64_t Lmax, int64_t nsplit, float rms_eps, float ln_eps, void* stream);
 
+/* ---- Entry points of the VARIANTS build only (landiff_amd/variants/liblandiff_hip_variants.so, built by
+ * `LD_BUILD_VARIANTS=1 landiff_amd/csrc/build.sh` with -DLD_VARIANTS): two other forms of the decode step that were built, are
+ * bit-identical to ld_llm_decode_forward, measured slower and are kept under test as measured alternatives.  The shipped
+ * library does not export them. ---- */
+#ifdef LD_VARIANTS
 /* The same step with all blocks in ONE persistent launch (ld_llm_fused.hip): identical bits, ~one launch instead of 144.
  * layers_dev: the ld_llm_layer table in DEVICE memory.  ctl: LD_LLM_FUSED_CTL_WORDS 32-bit words of device memory owned by
  * the caller, zeroed before the first step of a decode (word 0: steps done, word 1: error flag -- non-zero after a grid
@@ -291,6 +296,7 @@ int ld_llm_decode_blocks_chained(const ld_llm_layer* layers, int64_t n_layers, i
                                  void* gate, float* attn_ws, const float* cos_t, const float* sin_t, int64_t B, int64_t hidden,
                                  int64_t heads, int64_t mlp, int64_t Lmax, int64_t nsplit, float rms_eps, uint32_t* ctl,
                                  uint32_t epoch, void* stream0, void* stream1);
+#endif /* LD_VARIANTS */
 
 /* nn.Embedding lookup of *token (fp32 table [V][D]) -> bf16 features [B][D] (landiff/llm/modules/tokenizer.py:10-55). */
 int ld_llm_embed(const float* table, const int64_t* token, void* out, int64_t B, int64_t D, void* stream);

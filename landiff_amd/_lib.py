@@ -80,10 +80,6 @@ SIGNATURES: dict[str, list] = {
     "ld_vq_nearest": [P, I64, P, P, I64, I64, I64, P],
     "ld_llm_decode_forward": [P, I64, P, P, P, I32, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
                               c_float, c_float, P],
-    "ld_llm_decode_blocks_chained": [P, I64, I32, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_float, P, c_uint32, P, P],
-    "ld_llm_decode_blocks_fused": [P, I64, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_float, P, P],
-    "ld_llm_decode_forward_fused": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
-                                    c_float, c_float, P, P],
     "ld_llm_logits_to_probs": [P, P, P, I64, I32, c_float, c_float, P, P, I64, I32, c_float, P],
     "ld_llm_decode_advance": [P, P, P, P, P, P, P],
     "ld_llm_sample_advance": [P, P, P, I64, I32, c_float, c_float, P, P, I64, I32, c_float, P, P, P, P, P, P, P, P, I64, I64, P],
@@ -103,6 +99,21 @@ SIGNATURES: dict[str, list] = {
     "ld_t5_attn": [P, P, P, P, I64, P, P, I64, I64, P],
 }
 
+# entry points that only the variants build exports (include/landiff_hip.h under LD_VARIANTS; landiff_amd/csrc/build.sh with
+# LD_BUILD_VARIANTS=1 -> VARIANTS_LIB_PATH): bound when the loaded library has them
+VARIANT_SIGNATURES: dict[str, list] = {
+    "ld_llm_decode_blocks_chained": [P, I64, I32, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_float, P, c_uint32, P, P],
+    "ld_llm_decode_blocks_fused": [P, I64, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_float, P, P],
+    "ld_llm_decode_forward_fused": [P, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64,
+                                    c_float, c_float, P, P],
+}
+VARIANTS_LIB_PATH = os.path.join(_HERE, "variants", "liblandiff_hip_variants.so")
+
+
+def has_variants() -> bool:
+    """True when the loaded library is the variants build (LANDIFF_HIP_LIB pointed at it)."""
+    return hasattr(load(), "ld_llm_decode_blocks_chained")
+
 
 def load():
     """Load the shared library (once).  Raises LandiffHipError if it is missing."""
@@ -119,7 +130,9 @@ def load():
     if lib.ld_version() != ABI_VERSION:
         raise LandiffHipError(f"{LIB_PATH} reports ABI version {lib.ld_version()}, this binding was written for {ABI_VERSION}: "
                               "rebuild the library (__graft_entry__.build()) -- the argument lists would not match")
-    for name, argtypes in SIGNATURES.items():
+    sigs = dict(SIGNATURES)
+    sigs.update({k: v for k, v in VARIANT_SIGNATURES.items() if hasattr(lib, k)})
+    for name, argtypes in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = (c_char_p if name in ("ld_last_error", "ld_attn_last_kernel") else

@@ -1,23 +1,44 @@
 #!/bin/bash
-# Builds liblandiff_hip.so for gfx950 (cross-compiles without a GPU).
+# Builds liblandiff_hip.so for gfx950 (cross-compiles without a GPU): the shipped library, i.e. the kernels that run.
+# LD_BUILD_VARIANTS=1 also builds ../variants/liblandiff_hip_variants.so = the same sources with -DLD_VARIANTS plus the files that
+# hold only measured alternatives (128-row attention tile, round-1 attention pipeline, persistent / chained decode step,
+# software-pipelined and register-staged GEMM loops): bit-identical, measured slower, kept under test (tests/variants/) and
+# loaded by nothing else (LANDIFF_HIP_LIB selects it for a tools/ A/B run).
 set -e
 cd "$(dirname "$0")"
-OUT=../liblandiff_hip.so
-SRCS=$(ls ld_*.hip)
-mkdir -p obj
-pids=()
-for s in $SRCS; do
-  o=obj/${s%.hip}.o
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ ld_common.h -nt "$o" ] || [ ld_attn.h -nt "$o" ] || [ ld_llm_dev.h -nt "$o" ] || [ ../../include/landiff_hip.h -nt "$o" ]; then
-    extra=""
-    { [ "$s" = "ld_attn_pipe.hip" ] || [ "$s" = "ld_attn_p16.hip" ] || [ "$s" = "ld_attn_q64.hip" ] || [ "$s" = "ld_attn_q128.hip" ]; } && extra="-fno-slp-vectorize"
-    # the two forms of the decode step (one launch per operation / one persistent launch) must produce the same bits: no
-    # implicit mul+add fusion, whose outcome depends on the code around an expression (explicit fmaf / dot2 are unaffected)
-    { [ "$s" = "ld_llm.hip" ] || [ "$s" = "ld_llm_fused.hip" ]; } && extra="-ffp-contract=off"
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result $extra -c "$s" -o "$o" &
-    pids+=($!)
-  fi
+VARIANT_ONLY="ld_attn_pipe.hip ld_attn_q128.hip ld_llm_fused.hip"
+HDRS="ld_common.h ld_attn.h ld_llm_dev.h ../../include/landiff_hip.h"
+
+build_lib() {   # $1 = object dir, $2 = output, $3 = extra flags, $4.. = sources
+  local objdir=$1 out=$2 flags=$3; shift 3
+  mkdir -p "$objdir" "$(dirname "$out")"
+  local pids=() objs=()
+  for s in "$@"; do
+    local o=$objdir/${s%.hip}.o
+    objs+=("$o")
+    local stale=0
+    [ ! -f "$o" ] || [ "$s" -nt "$o" ] && stale=1
+    for h in $HDRS; do [ "$h" -nt "$o" ] && stale=1; done
+    if [ $stale = 1 ]; then
+      local extra=""
+      case $s in ld_attn_pipe.hip|ld_attn_p16.hip|ld_attn_q64.hip|ld_attn_q128.hip) extra="-fno-slp-vectorize";; esac
+      # the forms of the decode step (one launch per operation / chained / one persistent launch) must produce the same bits: no
+      # implicit mul+add fusion, whose outcome depends on the code around an expression (explicit fmaf / dot2 are unaffected)
+      case $s in ld_llm.hip|ld_llm_fused.hip) extra="-ffp-contract=off";; esac
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result $extra $flags -c "$s" -o "$o" &
+      pids+=($!)
+    fi
+  done
+  for p in "${pids[@]}"; do wait $p; done
+  hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+  echo "built $out"
+}
+
+LEAN=""
+for s in $(ls ld_*.hip); do
+  case " $VARIANT_ONLY " in *" $s "*) ;; *) LEAN="$LEAN $s";; esac
 done
-for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT obj/*.o
-echo "built $OUT"
+build_lib obj ../liblandiff_hip.so "" $LEAN
+if [ "${LD_BUILD_VARIANTS:-0}" = "1" ]; then
+  build_lib obj_variants ../variants/liblandiff_hip_variants.so "-DLD_VARIANTS=1" $(ls ld_*.hip)
+fi

@@ -339,10 +339,12 @@ __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
 
 }  // namespace
 
-int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st);   // ld_attn_pipe.hip
 int ld_attn_p16_launch(const AttnParams& p, hipStream_t st);     // ld_attn_p16.hip
 int ld_attn_q64_launch(const AttnParams& p, hipStream_t st);     // ld_attn_q64.hip
+#ifdef LD_VARIANTS   // measured alternatives, only in the variants build (build.sh: LD_BUILD_VARIANTS=1)
+int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st);   // ld_attn_pipe.hip
 int ld_attn_q128_launch(const AttnParams& p, hipStream_t st);    // ld_attn_q128.hip
+#endif
 
 // name of the kernel the calling thread's last ld_attn_fwd_bf16 launched (bench.py labels its roofline object with it)
 static thread_local const char* g_attn_last_kernel = "";
@@ -371,7 +373,7 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   static int var = -1;
   if (var < 0) {
     // tuning knob: 0 = default (pipelined 16x16x32 kernels of ld_attn_q64.hip / ld_attn_p16.hip for every unmasked problem of >= 6 key tiles, else the plain kernel),
-    // 8 = the pipelined 32x32x16 kernel of ld_attn_pipe.hip (round-1 default), 9 = plain kernel everywhere,
+    // 8 = the pipelined 32x32x16 kernel of ld_attn_pipe.hip (round-1 default; variants build only), 9 = plain kernel everywhere,
     // 1 / 4 = plain kernel with row sums on the matrix pipe / lean-register 4-waves form
     const char* e = getenv("LD_ATTN_VARIANT");
     var = e ? atoi(e) : 0;
@@ -381,18 +383,21 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   const int64_t nkt = (Nk + KT - 1) / KT;
   // LD_ATTN_Q64=0 (tuning knob): the 32-query-row wave tile of ld_attn_p16.hip instead of the 64-row one of ld_attn_q64.hip
   static const int q64 = getenv("LD_ATTN_Q64") ? atoi(getenv("LD_ATTN_Q64")) : 1;
-  // LD_ATTN_Q128 (tuning knob): 1 = the 128-query-row, one-wave-per-SIMD tile of ld_attn_q128.hip (512 rows per workgroup: only
-  // for problems with enough query rows to fill the chip with such workgroups); 2 = every unmasked problem of >= 6 key tiles.
+#ifdef LD_VARIANTS
+  // LD_ATTN_Q128 (variants build only): 1 = the 128-query-row, one-wave-per-SIMD tile of ld_attn_q128.hip (512 rows per workgroup:
+  // only for problems with enough query rows to fill the chip with such workgroups); 2 = every unmasked problem of >= 6 key tiles.
   // Like every knob it is read once, or per call under LD_TUNING=1 (ld_common.h) so that one process can time both tiles.
   static int k_q128 = LD_KNOB_UNSET;
   const int q128 = ld_knob("LD_ATTN_Q128", 0, &k_q128);
   if (var == 0 && !fid_k && nkt >= 6 && (q128 == 2 || (q128 == 1 && B * H * ((Npad + 511) / 512) >= 512)))
     return ld_attn_q128_launch(p, st);
+#endif
   if (var == 0 && !fid_k && nkt >= 6 && q64) return ld_attn_q64_launch(p, st);
   if (var == 0 && !fid_k && nkt >= 6) return ld_attn_p16_launch(p, st);                  // any tile count
-  if (var == 8 && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) {                              // (the round-1 kernel: tile counts 4 m + 2)
-    return ld_attn_pipe2_launch(p, st);
-  } else if (var == 1) {
+#ifdef LD_VARIANTS
+  if (var == 8 && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) return ld_attn_pipe2_launch(p, st);   // (the round-1 kernel: tile counts 4 m + 2)
+#endif
+  if (var == 1) {
     g_attn_last_kernel = "ld_attn_kernel<1,true,false,true,2>";
     hipLaunchKernelGGL((ld_attn_kernel<1, true, false, true, 2>), grid, block, s1, st, p);
   } else if (var == 4) {

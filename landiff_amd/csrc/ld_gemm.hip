@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
   }
 }
 
+#ifdef LD_VARIANTS   // measured alternatives, not in the shipped library (build.sh: LD_BUILD_VARIANTS=1)
 // ------------------------------------------------------------------------------------------------
 // Software-pipelined main loop (round 4; LD_GEMM_SP=1): the 256 x 256 x 64 tile / 8 waves (2 x 4, 128 x 64 per wave) /
 // 16x16x32 MFMAs of ld_gemm8p_kernel, but every wave pipelines ITS OWN fragment reads under its own MFMAs and the workgroup
@@ -1232,6 +1233,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm_sp_kernel(GemmParams p) {
   }
 #undef SPF
 }
+#endif  // LD_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) x fp8 -> fp32 GEMM for the DiT's four large linear layers (BASELINE config 5; never the headline
@@ -1413,6 +1415,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm_f8_kernel(GemmParams p) {
   gemm_epilogue<MI, NI, EPI>(p, acc, smem, wave, lane, row0, col0);
 }
 
+#ifdef LD_VARIANTS
 // ------------------------------------------------------------------------------------------------
 // One-wave-per-SIMD, register-staged main loop on v_mfma_f32_32x32x16_bf16 (the round-1 default, LD_GEMM_TILE=11; see
 // profiles/r01d_gemm_vs_vendor_library.txt for the measurements that shaped it): 256x256 tile, 4 waves x 128x128 = 4x4
@@ -1561,6 +1564,7 @@ __global__ __launch_bounds__(256, 1) void ld_gemm_w4r_kernel(GemmParams p) {
   gemm_epilogue<4, 2, EPI>(p, acc[0], smem, wave, lane, m0 + wr * 128, n0 + wc * 128);
   gemm_epilogue<4, 2, EPI>(p, acc[1], smem, wave, lane, m0 + wr * 128, n0 + wc * 128 + 64);
 }
+#endif  // LD_VARIANTS
 
 template <auto Kernel>
 int launch_kernel(const char* what, dim3 grid, dim3 block, int smem, hipStream_t stream, const GemmParams& p) {
@@ -1631,6 +1635,7 @@ int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
   }
   dim3 grid((unsigned)((persist && ntiles > ncu) ? ncu : ntiles)), block(512);
   const int epi = pick_epilogue(p);
+#ifdef LD_VARIANTS
   // LD_GEMM_SP=1: the software-pipelined loop (with LD_TUNING=1 re-read per call: tools/gemm_ab.py times both loops alternately)
   static int k_sp = LD_KNOB_UNSET;
   if (!conv && ld_knob("LD_GEMM_SP", 0, &k_sp) == 1 && (p.K / BK) % 2 == 0 && p.K / BK >= 4) {
@@ -1642,6 +1647,7 @@ int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
       default: return launch_kernel<ld_gemm_sp_kernel<EPI_GENERIC>>("ld_gemm_sp", grid, block, SMEM, stream, p);
     }
   }
+#endif
   if (epi == EPI_QKV) {
     LD_REQUIRE(!conv, "ld_gemm_qkv_heads: not a convolution epilogue");
     return launch_kernel<ld_gemm8p_kernel<false, EPI_QKV>>("ld_gemm_qkv_heads", grid, block, SMEM, stream, p);
@@ -1658,6 +1664,7 @@ int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
   }
 }
 
+#ifdef LD_VARIANTS
 int launch_w4r(const GemmParams& p, hipStream_t stream) {
   constexpr int SMEM = 2 * (256 + 256) * 64 * 2;   // two 64 KB K-tile slots (the epilogue staging reuses them)
   const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
@@ -1669,6 +1676,7 @@ int launch_w4r(const GemmParams& p, hipStream_t stream) {
     default: return launch_kernel<ld_gemm_w4r_kernel<EPI_GENERIC>>("ld_gemm_w4r", grid, block, SMEM, stream, p);
   }
 }
+#endif  // LD_VARIANTS
 
 // Bytes of the zero-bordered channels-last input a convolution's A-address generator walks: [(T + kT - 1)][Hp][Wp][Cin] bf16.
 long conv_input_bytes(const GemmParams& p) {
@@ -1716,12 +1724,9 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = fa
     g_last_route = ROUTE_128_2STAGE;
     return dry_run ? 0 : launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
   }
-  // default for the large linear layers: the register-staged 4-wave loop (qkv / 4h / 4h->h GEMMs 3-6 % faster than the
-  // 8-wave kernel); the gated-residual epilogue on a short K (DiT proj, K = 1920) hides its operand loads better with 8 waves
-  // (round 1 default for the large linear layers: the register-staged 4-wave loop on 32x32x16 MFMAs, LD_GEMM_TILE=11; the
-  //  8-wave LDS-DMA kernel on 16x16x32 MFMAs is 3-8 % faster than it on all four DiT shapes: both are bound by the power
-  //  governor, and the 16x16x32 form costs less energy per FLOP)
-  const bool w4r_default = false;
+  // (round 1 default for the large linear layers: the register-staged 4-wave loop on 32x32x16 MFMAs, LD_GEMM_TILE=11, now only
+  //  in the variants build; the 8-wave LDS-DMA kernel on 16x16x32 MFMAs is 3-8 % faster than it on all four DiT shapes: both are
+  //  bound by the power governor, and the 16x16x32 form costs less energy per FLOP)
   static int use8p = -1;
   if (use8p < 0) { const char* e = getenv("LD_GEMM_8P"); use8p = e ? atoi(e) : 1; }
   auto big = [&](const GemmParams& q) {
@@ -1730,10 +1735,12 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = fa
       g_last_route = ROUTE_256_8PHASE;
       return dry_run ? 0 : launch_8p(q, conv, stream);
     }
-    if (!q.q_out && (cfg == 11 || w4r_default) && pp_ok && !conv) {
+#ifdef LD_VARIANTS
+    if (!q.q_out && cfg == 11 && pp_ok && !conv) {
       g_last_route = ROUTE_256_W4R;
       return dry_run ? 0 : launch_w4r(q, stream);
     }
+#endif
     g_last_route = ROUTE_256_2STAGE;      // (also the fused qkv split with LD_GEMM_8P=0: it lives in the 16x16x32 kernels only)
     return dry_run ? 0 : launch_cfg<256, 256, 2, 4, 2>(q, conv, stream);
   };

@@ -1085,6 +1085,7 @@ LD_API int ld_llm_decode_forward(const ld_llm_layer* layers, int64_t n_layers, c
                  nullptr, 0.f, stream);
 }
 
+#ifdef LD_VARIANTS   // the dependent-launch form of a decode step: measured slower, only in the variants build
 namespace {
 // the register GEMV in its dependent-launch form (B = 2): variant choice of launch_gemv_b, <= 128 registers, <= 512 workgroups
 template <int R, int J, bool GATED, bool NORM>
@@ -1158,6 +1159,7 @@ LD_API int ld_llm_decode_blocks_chained(const ld_llm_layer* layers, int64_t n_la
   }
   return rc;
 }
+#endif  // LD_VARIANTS
 
 LD_API int ld_llm_logits_to_probs(const float* logits, float* probs, float* cfg_logits, int64_t V, int32_t guided,
                                   float scale, float temperature, const int32_t* pos, const int32_t* allowed,

@@ -55,7 +55,9 @@ struct KvRows { u32x4_t k[KV_MAXIT], v[KV_MAXIT]; };
 // captured graph), so that all of them keep producing the same bits; workgroups of unused splits leave at once.
 // t1 / t2 / t4: longest context served by 1 / 2 / 4 splits (LD_KV_SPLIT_T=t1,t2,t4; LD_KV_SPLIT_T=0,0,0: always nsplit_max).
 struct KvSplitRule { int t1, t2, t4; };
-constexpr int KV_SPLIT_T1 = 128, KV_SPLIT_T2 = 384, KV_SPLIT_T4 = 768;      // defaults: tools/kv_attn_sweep.py
+// defaults from tools/kv_attn_sweep.py (profiles/r05_llm_kv_attn_split_sweep.txt): one split is fastest up to ~110 keys (no merge:
+// -1.5 us), two are never the best, four win up to ~230 keys, beyond that the full eight (more would not fit one round of the chip)
+constexpr int KV_SPLIT_T1 = 112, KV_SPLIT_T2 = 112, KV_SPLIT_T4 = 232;
 __host__ __device__ inline int kv_eff_splits(int L, int nsplit_max, KvSplitRule r) {
   int ns = L <= r.t1 ? 1 : L <= r.t2 ? 2 : L <= r.t4 ? 4 : nsplit_max;
   if (ns > nsplit_max) ns = nsplit_max;

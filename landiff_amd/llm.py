@@ -19,7 +19,7 @@ import time
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .config import LLMConfig
 
 BF = torch.bfloat16
@@ -128,11 +128,13 @@ class LLMRunner:
         self.attn_ws = torch.zeros(B * H * (self.nsplit * 130 + 1), device=device, dtype=torch.float32)
         self._graph = None
         self._layer_table = None
-        # Three forms of a decode step's blocks, identical bits (tests/test_gpu_stages.py, tests/test_gpu_fullsize.py):
-        #   "chain"    one launch per operation on the current stream (5 per block);
+        # Three forms of a decode step's blocks, identical bits (tests/variants/variant_cases.py):
+        #   "chain"    one launch per operation on the current stream (5 per block) -- what the shipped library has;
         #   "chained"  the same launches alternating between two streams with device-side dependencies (every launch requests
         #              its first weight rows while its predecessor is still running; ld_llm_decode_blocks_chained);
-        #   "fused"    all blocks in one persistent launch with grid barriers (ld_llm_fused.hip; measured slower, opt-in).
+        #   "fused"    all blocks in one persistent launch with grid barriers (ld_llm_fused.hip).
+        # The last two were measured slower and live in the VARIANTS build of the library only (landiff_amd/_lib.py:
+        # VARIANTS_LIB_PATH, selected with LANDIFF_HIP_LIB): asking for them on the shipped library raises.
         # "chained" and "fused" need the GPU to themselves (their workgroups wait for other workgroups): callers that decode
         # UNDER another stream's kernels (generate_many, the streaming loop) pass mode="chain".  LD_LLM_DECODE overrides the default.
         self.decode_mode = os.environ.get("LD_LLM_DECODE", "chain")
@@ -295,6 +297,10 @@ class LLMRunner:
         # an unsupported shape falls back to "chain"
         mode = self.decode_mode if mode is None else mode
         assert mode in ("chain", "chained", "fused"), mode
+        if mode != "chain" and not _lib.has_variants():
+            raise _lib.LandiffHipError(f"decode mode {mode!r} needs the variants build of the library (LD_BUILD_VARIANTS=1 "
+                                       f"landiff_amd/csrc/build.sh, then LANDIFF_HIP_LIB={_lib.VARIANTS_LIB_PATH}); the shipped library "
+                                       "has the per-operation chain only")
         if (mode == "fused" and not self.fused_supported) or (mode == "chained" and (not self.chained_supported or use_graph)):
             mode = "chain"
         self._mode = mode

@@ -13,14 +13,24 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def test_library_exports_every_declared_symbol():
+    """The shipped library exports exactly what include/landiff_hip.h declares outside its LD_VARIANTS section (= _lib.SIGNATURES);
+    the variants build exports those plus the section's entry points (= _lib.VARIANT_SIGNATURES)."""
+    import subprocess
     from landiff_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "landiff_hip.h")).read()
-    declared = set(re.findall(r"\b(ld_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 24
+    var_sec = re.search(r"#ifdef LD_VARIANTS\n(.*?)#endif /\* LD_VARIANTS \*/", hdr, re.S).group(1)
+    names = lambda text: set(re.findall(r"\b(ld_[a-z0-9_]+)\s*\(", text))
+    variant_only = names(var_sec)
+    declared = names(hdr) - variant_only
+    assert len(declared) >= 24 and variant_only == set(_lib.VARIANT_SIGNATURES), variant_only ^ set(_lib.VARIANT_SIGNATURES)
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/landiff_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    exported = lambda path: set(re.findall(r" T (ld_[a-z0-9_]+)", subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout))
+    assert exported(_lib.LIB_PATH) == declared, exported(_lib.LIB_PATH) ^ declared          # nothing undeclared, no variant entry point
+    if os.path.exists(_lib.VARIANTS_LIB_PATH):
+        assert exported(_lib.VARIANTS_LIB_PATH) == declared | variant_only
     assert lib.ld_version() == _lib.ABI_VERSION == int(re.search(r"#define LD_ABI_VERSION (\d+)", hdr).group(1))
     assert ctypes.sizeof(_lib.Epilogue) == 120          # layout of ld_epilogue_t
 
@@ -58,9 +68,18 @@ def test_conv_route_keeps_large_inputs_off_the_8_phase_kernel():
 
 def test_decode_step_forms_validate_without_gpu():
     """The alternative forms of a decode step's blocks (one persistent launch / dependent launches on two streams) reject null
-    pointers and shapes outside their register forms before any HIP call: LD_ERR_INVALID (-1) / LD_ERR_UNSUPPORTED (-3)."""
+    pointers and shapes outside their register forms before any HIP call: LD_ERR_INVALID (-1) / LD_ERR_UNSUPPORTED (-3).
+    They live in the variants build of the library only (a second handle here: the shipped library stays the one _lib binds)."""
+    import subprocess
     from landiff_amd import _lib
-    lib = _lib.load()
+    if not os.path.exists(_lib.VARIANTS_LIB_PATH):
+        subprocess.run(["bash", os.path.join(ROOT, "landiff_amd", "csrc", "build.sh")], check=True, env=dict(os.environ, LD_BUILD_VARIANTS="1"))
+    assert not hasattr(_lib.load(), "ld_llm_decode_blocks_fused")         # the shipped library does not carry them
+    lib = ctypes.CDLL(_lib.VARIANTS_LIB_PATH)
+    for name, argtypes in _lib.VARIANT_SIGNATURES.items():
+        getattr(lib, name).argtypes = argtypes
+        getattr(lib, name).restype = ctypes.c_int
+    lib.ld_last_error.restype = ctypes.c_char_p
     P = ctypes.c_void_p
     fake = [P(4096)] * 9                                            # pos, x, qkv, att, gate, attn_ws, cos, sin (+1): never dereferenced
     rc = lib.ld_llm_decode_blocks_fused(None, 24, *fake[:8], 2, 2048, 16, 11008, 1762, 8, 1e-5, P(4096), None)

@@ -119,29 +119,6 @@ def test_llm_full_size_decode_properties(cuda):
     assert not torch.equal(t1, t4)
 
 
-def test_llm_full_size_chained_and_fused_blocks_equal_chain(cuda):
-    """24 x 2048: the dependent-launch form (two streams, device-side waits, 120 launches per step) and the persistent one-launch
-    form (256 workgroups, 143 grid barriers per step) of a decode step against the per-operation chain: one frame's decode
-    (~330 steps), ids, final logits and the KV cache bit for bit."""
-    from landiff_amd.config import LLMConfig
-    from landiff_amd.llm import LLMRunner
-    from landiff_amd.weights import init_state, llm_spec
-    cfg = LLMConfig()
-    run = LLMRunner(init_state(llm_spec(cfg), 5, dtype=torch.bfloat16, device=cuda), cfg, cuda)
-    assert run.fused_supported and run.chained_supported
-    text = torch.randn(48, cfg.text_dim, device=cuda, generator=torch.Generator(device=cuda).manual_seed(6))
-    res = {}
-    for mode in ("chain", "chained", "fused"):
-        ids = run.sample(text, guidance_scale=7.5, seed=42, num_frames=1, mode=mode).clone()
-        torch.cuda.synchronize()
-        res[mode] = (ids, run.logits.clone(), run.kc[0].clone(), run.vc[-1].clone())
-    assert int(run.fused_ctl[0]) > 300 and int(run.fused_ctl[1]) == 0
-    assert run._chain_epoch > 300 and int(run.chain_ctl[0]) == 0
-    for mode in ("chained", "fused"):
-        for u, v in zip(res["chain"], res[mode]):
-            assert torch.equal(u, v), mode
-
-
 def test_dit_layer_full_shape_vs_oracle(cuda):
     """One AdaLN layer of the main DiT at the BASELINE shape (B=2 CFG pair, 17 776 tokens, hidden 1920, 30 heads) through
     the HIP path -- pipelined attention kernel, specialised GEMM epilogues, M-split launches -- against the fp32 oracle on

@@ -325,30 +325,6 @@ def test_llm_first_frame_conditioning(cuda, setup):
     assert n_cmp == n_vis - c.iframe_len and agree >= 0.8, (n_cmp, agree, len(flips))
 
 
-def test_llm_chained_and_fused_blocks_equal_per_operation_chain_tiny(cuda, setup):
-    """The two other forms of a decode step's blocks -- dependent launches on two streams (ld_llm_decode_blocks_chained) and one
-    persistent launch with grid barriers (ld_llm_decode_forward_fused) -- against the per-operation chain on the tiny config: ids,
-    every step's CFG logits and the KV cache bit for bit."""
-    from landiff_amd.llm import LLMRunner
-    cfg, st = setup
-    c = cfg.llm
-    text = torch.randn(5, c.text_dim, generator=torch.Generator().manual_seed(19))
-    run = LLMRunner(st["llm"], c, cuda, max_text=32, max_frames=c.segment_length)
-    assert run.fused_supported and run.chained_supported
-    res = {}
-    for mode in ("chain", "chained", "fused"):
-        log = []
-        ids = run.sample(text, num_frames=c.segment_length, guidance_scale=7.5, seed=31, logits_log=log, mode=mode).clone()
-        torch.cuda.synchronize()
-        res[mode] = (ids, torch.cat(log, 0), run.kc[0].clone(), run.vc[-1].clone())
-        assert run._mode == mode
-    assert int(run.fused_ctl[0]) > 0 and int(run.fused_ctl[1]) == 0          # steps ran through the persistent launch, no time-out
-    assert run._chain_epoch > 0 and int(run.chain_ctl[0]) == 0               # ... and through the chained launches
-    for mode in ("chained", "fused"):
-        for u, v in zip(res["chain"], res[mode]):
-            assert torch.equal(u, v), mode
-
-
 def test_llm_native_step_equals_per_op_step(cuda, setup):
     """ld_llm_decode_forward (the whole step queued by one native call) issues exactly the launches of the per-op path:
     same tokens from the same seed, eager and graph-replayed, and the same logits bit for bit on one step."""

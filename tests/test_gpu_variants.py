@@ -157,8 +157,30 @@ print("HASH", h.hexdigest())
 """ % ROOT
 
 
-def _run(snippet, env):
+def variants_lib() -> str:
+    """Path of the variants build of the library (the measured alternatives live only there); __graft_entry__.build() makes it, and
+    a tree that lacks it gets it built here (hipcc is on the GPU box too; a few minutes, once)."""
+    path = os.path.join(ROOT, "landiff_amd", "variants", "liblandiff_hip_variants.so")
+    if not os.path.exists(path):
+        e = dict(os.environ, LD_BUILD_VARIANTS="1")
+        subprocess.run(["bash", os.path.join(ROOT, "landiff_amd", "csrc", "build.sh")], env=e, check=True, timeout=3000)
+    return path
+
+
+def _needs_variants(env) -> bool:
+    return (env.get("LD_GEMM_TILE") == "11" or env.get("LD_GEMM_SP") == "1" or env.get("LD_ATTN_VARIANT") == "8"
+            or env.get("LD_ATTN_Q128", "0") != "0")
+
+
+def _env(env):
     e = dict(os.environ); e.update(env)
+    if _needs_variants(env):
+        e["LANDIFF_HIP_LIB"] = variants_lib()
+    return e
+
+
+def _run(snippet, env):
+    e = _env(env)
     r = subprocess.run([sys.executable, "-c", snippet], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("WORST")][-1]
@@ -203,11 +225,22 @@ def test_attention_wave_tiles_bit_identical(cuda):
     outs = []
     for env in ({"LD_ATTN_Q128": "0"}, {"LD_ATTN_Q64": "0", "LD_ATTN_Q128": "0"}, {"LD_ATTN_Q128": "2"},
                 {"LD_ATTN_Q128": "2", "LD_ATTN_NPRE": "36"}, {"LD_ATTN_Q128": "2", "LD_ATTN_NPRE": "52"}):
-        e = dict(os.environ); e.update(env)
+        e = _env(env)                       # (the first two run on the shipped library, the 128-row tile on the variants build)
         r = subprocess.run([sys.executable, "-c", ATTN_HASH_SNIPPET], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
     assert all(o == outs[0] for o in outs[1:]), outs
+
+
+def test_variants_build_suite(cuda):
+    """tests/variants/variant_cases.py in a child pytest process on the variants build of the library: the 128-query-row attention
+    tile (15 shapes, overflow fallback, bit-identity with the 64-row tile) and the chained / persistent forms of the decode step
+    (bit-identical ids, logits and KV cache, tiny and full size)."""
+    e = dict(os.environ, LANDIFF_HIP_LIB=variants_lib())
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "variants", "variant_cases.py"), "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider"], env=e, capture_output=True, text=True, timeout=2400, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
 
 
 def test_groupnorm_apply_forms(cuda):
