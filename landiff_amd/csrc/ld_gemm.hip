@@ -66,6 +66,9 @@ struct GemmParams {
   const bf16_t* qn_w; const bf16_t* qn_b; const bf16_t* kn_w; const bf16_t* kn_b;   // QK-LayerNorm(64) weights
   int heads, Ntok, Npad;
   float qk_eps;
+  // 8-phase kernels: the launch covers tiles [tile_begin, tile_end) of the 256 x 256 raster (tile_end == 0: all of them).  The
+  // whole rounds of the chip go to ld_gemm8p_kernel, the partial last round to ld_gemm8p_n128_kernel as 256 x 128 half tiles.
+  int tile_begin, tile_end;
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
@@ -734,6 +737,12 @@ __device__ __forceinline__ void stage_pieces(const bf16_t* base, int bytes, char
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + OFF + 1024), 16, o1, ko, 0, 0);
 }
 
+template <int OFF>
+__device__ __forceinline__ void stage_piece1(const bf16_t* base, int bytes, char* lds, uint32_t o0, int ko) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + OFF), 16, o0, ko, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 8-phase main loop (round 3 default for the 256 x 256 tile; LD_GEMM_8P=0 selects the two-stage loop of ld_gemm_kernel): the
 // 256x256x64 tile / 8 waves (2 x 4, 128 x 64 per wave) / 16x16x32 MFMAs of ld_gemm_kernel<256,256,2,4,...,M16> with the
@@ -953,7 +962,8 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
 
   set_offsets(0, true);
   bool k0_staged = false;                                 // K-tile 0 of the tile about to start is already on its way
-  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+  const int v_end = p.tile_end > 0 ? p.tile_end : ntiles; // (the tiles behind it: ld_gemm8p_n128_kernel)
+  for (int v = p.tile_begin + blockIdx.x; v < v_end; v += gridDim.x) {
     int m0, n0;
     tile_origin(v, m0, n0);
 #ifdef LD_GEMM_TRACE
@@ -998,7 +1008,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
     bool hooked = false;
     Src nsrc = src;
     k0_staged = false;
-    if (PREFETCH && !CONV && vn < ntiles) {               // (a convolution's next-tile A offsets would need a second register set)
+    if (PREFETCH && !CONV && vn < v_end) {                // (a convolution's next-tile A offsets would need a second register set)
       int m1, n1;
       tile_origin(vn, m1, n1);
       nsrc = tile_src(m1, n1);
@@ -1024,7 +1034,233 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
       }
     }
 #endif
-    if (vn < ntiles) __syncthreads();                     // the staging region is free again before buffer-1 slots are re-staged
+    if (vn < v_end) __syncthreads();                      // the staging region is free again before buffer-1 slots are re-staged
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same 8-phase loop on 256 x 128 HALF tiles (round 5): the partial last round of a launch.  A GEMM whose 256 x 256 tiles
+// do not fill whole rounds of the chip used to send its last tile ROWS to a second launch of 128 x 128 two-stage tiles: two
+// workgroups per CU that share the matrix pipe, 1.4 quarter tiles per CU on average and two on the CUs that set the time -- 9 % of
+// a DiT layer-call's GEMM time for 4 % of its tiles (profiles/r04_gemm_tile_trace.txt).  Here the r < 128 tiles behind the whole
+// rounds (the tiles [tile_begin, ntiles) of the SAME raster, so the main launch is exactly `rounds` tiles per CU) are cut in two
+// along N and run one per CU: 2 r <= 256 workgroups, one round, each half the work of a full tile.
+//   * 8 waves as 4 x 2, wave tile 64 x 64 = [4][4] accumulators; per K-tile and wave 8 A + 8 W fragment reads for 32 MFMAs (the
+//     2 x 4 layout of the full tile on 128 columns would need 16 + 4) -- 128 KB of LDS reads per K-tile against 1088 MFMA cycles;
+//   * LDS: 2 K-tile buffers x (A_0, A_1: 16 KB = for all four wave rows wr the 32 tile rows wr * 64 + h * 32 ..; W_0, W_1: 8 KB =
+//     for both wave columns wc the 32 tile columns wc * 64 + g * 32 ..) = 96 KB; a wave stages two 1 KB pieces of every A half
+//     and one of every W half: 6 LDS-DMA instructions per K-tile;
+//   * phases, staging order, counted vmcnt (3 = A_0 + W_0 of K-tile t + 2), the one-barrier skew between waves 0-3 and 4-7 (the
+//     two waves of a SIMD), persistent loop and epilogues: those of ld_gemm8p_kernel; same dot products in the same order ->
+//     the same bits as any other tiling of the GEMM.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void ld_gemm8p_n128_kernel(GemmParams p) {
+  constexpr int BM = 256, BNF = 256;                      // the raster is the full tiles'
+  constexpr int SLOT_A = 128 * 128, SLOT_B = 64 * 128, KBUF = 2 * SLOT_A + 2 * SLOT_B;     // 48 KB per K-tile: A0 A1 B0 B1
+  constexpr int EPI_BYTES = (EPI == EPI_QKV) ? 8 * QKV_REGION : 8 * 32 * CW_STRIDE * 4;
+  constexpr int EPI_OFF = (LD_LDS_TOTAL - EPI_BYTES) & ~15;
+  constexpr bool PREFETCH = EPI_OFF >= KBUF;
+  constexpr bool SWAPACC = EPI != EPI_QKV;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const bool late = wave >= 4;                            // the second wave of each SIMD runs one barrier behind the first
+
+  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BNF - 1) / BNF;
+  const int ntiles = nbm * nbn;
+  const int gm_sz = p.group_m;
+  auto tile_origin = [&](int v, int& m0, int& n0) {       // (ld_gemm8p_kernel's)
+    const int bid = xcd_remap(v, ntiles);
+    const int per_group = gm_sz * nbn;
+    const int group = bid / per_group, in_group = bid - group * per_group;
+    const int first_m = group * gm_sz;
+    const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+    m0 = p.m_begin + (first_m + in_group % rows_here) * BM;
+    n0 = (in_group / rows_here) * BNF;
+  };
+  const int v_end = p.tile_end > 0 ? p.tile_end : ntiles;
+  const int nhalf = 2 * (v_end - p.tile_begin);           // work items: half u of tile tile_begin + (u >> 1)
+  auto half_origin = [&](int u, int& m0, int& n0) {
+    tile_origin(p.tile_begin + (u >> 1), m0, n0);
+    n0 += (u & 1) * 128;
+  };
+
+  const auto clip = [](long v) { return (int)(v < 0x7fffffffL ? v : 0x7fffffffL); };
+  struct Src { const bf16_t* a; const bf16_t* w; int a_bytes, w_bytes; };
+  auto tile_src = [&](int m0, int n0) {
+    Src s;
+    s.a = p.A + (long)m0 * p.lda;
+    s.w = p.W + (long)n0 * p.K;
+    s.a_bytes = clip(((long)(p.M - m0) * p.lda) * 2);
+    s.w_bytes = n0 < p.N ? clip(((long)(p.N - n0) * p.K) * 2) : 0;
+    return s;
+  };
+  uint32_t offA[2][2], offW[2];                           // A: [half][piece], W: [half]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = wave * 16 + i * 8 + (lane >> 3);       // local row of an A slot, 0 .. 127
+    const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int tm = (lr >> 5) * 64 + h * 32 + (lr & 31);
+      offA[h][i] = (uint32_t)(((long)tm * p.lda + chunk * 8) * 2);
+    }
+  }
+  {
+    const int lr = wave * 8 + (lane >> 3);                // local row of a W slot, 0 .. 63
+    const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int tn = (lr >> 5) * 64 + g * 32 + (lr & 31);
+      offW[g] = (uint32_t)(((long)tn * p.K + chunk * 8) * 2);
+    }
+  }
+  const int nk = p.K / BK;
+  char* const a_piece = smem + wave * 2048;               // + buffer * KBUF + h * SLOT_A (+ 1024 for the second piece)
+  char* const w_piece = smem + 2 * SLOT_A + wave * 1024;  // + buffer * KBUF + g * SLOT_B
+  Src src;
+  auto stage_a = [&](const Src& s, auto bufc, auto hc, int kt) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(hc)::value * SLOT_A;
+    stage_pieces<OFF>(s.a, s.a_bytes, a_piece, offA[decltype(hc)::value][0], offA[decltype(hc)::value][1], kt * (BK * 2));
+  };
+  auto stage_w = [&](const Src& s, auto bufc, auto gc, int kt) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(gc)::value * SLOT_B;
+    stage_piece1<OFF>(s.w, s.w_bytes, w_piece, offW[decltype(gc)::value], kt * (BK * 2));
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto stage_ktile0 = [&](const Src& s) {
+    stage_a(s, I0{}, I0{}, 0); stage_w(s, I0{}, I0{}, 0); stage_w(s, I0{}, I1{}, 0); stage_a(s, I0{}, I1{}, 0);
+  };
+
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c = (ks * 4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7);
+    rdA[ks] = (wr * 32 + (lane & 15)) * 128 + (c << 4);
+    rdB[ks] = 2 * SLOT_A + (wc * 32 + (lane & 15)) * 128 + (c << 4);
+  }
+  f32x4_t acc[4][4];
+  bf16x8_t a[2][2], b0[2][2], b1[2][2];
+  auto read_a = [&](auto bufc, auto hc) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(hc)::value * SLOT_A;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[i][ks] = *(const bf16x8_t*)(smem + rdA[ks] + OFF + i * 2048);
+  };
+  auto read_b = [&](auto bufc, auto gc, bf16x8_t (&b)[2][2]) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(gc)::value * SLOT_B;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b[j][ks] = *(const bf16x8_t*)(smem + rdB[ks] + OFF + j * 2048);
+  };
+  bool wave_live = true;
+  auto mma = [&](auto hc, auto gc, bf16x8_t (&b)[2][2]) {
+    constexpr int H = decltype(hc)::value, G = decltype(gc)::value;
+    __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0), as the builtin (see ld_gemm8p_kernel)
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_live) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[H * 2 + i][G * 2 + j] = SWAPACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[H * 2 + i][G * 2 + j], 0, 0, 0)
+                                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[H * 2 + i][G * 2 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto ktile = [&](auto bufc, int kt) {
+    constexpr int B = decltype(bufc)::value;
+    using Bc = std::integral_constant<int, B>;
+    using Nc = std::integral_constant<int, B ^ 1>;
+    // ph0
+    read_b(Bc{}, I0{}, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(Bc{}, I0{});
+    if (kt + 1 < nk) stage_w(src, Nc{}, I1{}, kt + 1);
+    bar(); mma(I0{}, I0{}, b0); bar();
+    // ph1
+    read_b(Bc{}, I1{}, b1);
+    if (kt + 1 < nk) stage_a(src, Nc{}, I1{}, kt + 1);
+    bar(); mma(I0{}, I1{}, b1); bar();
+    // ph2
+    read_a(Bc{}, I1{});
+    if (kt + 2 < nk) stage_a(src, Bc{}, I0{}, kt + 2);
+    bar(); mma(I1{}, I1{}, b1); bar();
+    // ph3
+    if (kt + 2 < nk) {
+      stage_w(src, Bc{}, I0{}, kt + 2);
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // K-tile kt + 1 has landed; A_0 (2 pieces) / W_0 (1) of kt + 2 stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar(); mma(I1{}, I0{}, b0); bar();
+  };
+
+  bool k0_staged = false;
+  for (int u = blockIdx.x; u < nhalf; u += gridDim.x) {
+    int m0, n0;
+    half_origin(u, m0, n0);
+    const int un = u + gridDim.x;
+    if (n0 >= p.N) continue;                              // the empty half of a tile in a half-wide last column (never prefetched for)
+    src = tile_src(m0, n0);
+    wave_live = n0 + wc * 64 < p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    if (!k0_staged) stage_ktile0(src);
+    if (nk > 1) {
+      stage_a(src, I1{}, I0{}, 1); stage_w(src, I1{}, I0{}, 1);
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    if (late) bar();
+
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(I0{}, kt);
+      ktile(I1{}, kt + 1);
+    }
+    if (kt < nk) ktile(I0{}, kt);
+    if (!late) bar();
+    __syncthreads();
+
+    bool hooked = false;
+    Src nsrc = src;
+    k0_staged = false;
+    if (PREFETCH && un < nhalf) {
+      int m1, n1;
+      half_origin(un, m1, n1);
+      if (n1 < p.N) { nsrc = tile_src(m1, n1); k0_staged = true; }
+    }
+    auto hook = [&]() {
+      if (!hooked && k0_staged) stage_ktile0(nsrc);
+      hooked = true;
+    };
+    if constexpr (EPI == EPI_QKV) qkv_epilogue16<2>(p, acc, smem + EPI_OFF, wave, lane, m0 + wr * 64, n0 + wc * 64, hook);
+    else gemm_epilogue16<2, EPI, 4, SWAPACC>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wr * 64, n0 + wc * 64, hook);
+    hook();
+    if (un < nhalf) __syncthreads();
   }
 }
 
@@ -1624,7 +1860,7 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
 int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
   constexpr int SMEM = LD_LDS_TOTAL;                       // 2 x 64 KB K-tile buffers; epilogue staging at the end of the 160 KB
   const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
-  const long ntiles = (long)nbm * nbn;
+  const long ntiles = (p.tile_end > 0 ? p.tile_end : (long)nbm * nbn) - p.tile_begin;     // tiles of THIS launch
   // persistent tiles: one workgroup per CU (LD_GEMM_PERSIST=0: one workgroup per tile)
   static int persist = -1, ncu = 0;
   if (persist < 0) {
@@ -1661,6 +1897,21 @@ int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
     case EPI_GELU: return launch_kernel<ld_gemm8p_kernel<false, EPI_GELU>>("ld_gemm8p", grid, block, SMEM, stream, p);
     case EPI_GATE: return launch_kernel<ld_gemm8p_kernel<false, EPI_GATE>>("ld_gemm8p", grid, block, SMEM, stream, p);
     default: return launch_kernel<ld_gemm8p_kernel<false, EPI_GENERIC>>("ld_gemm8p", grid, block, SMEM, stream, p);
+  }
+}
+
+// the partial last round of a launch as 256 x 128 half tiles, one per workgroup (ld_gemm8p_n128_kernel)
+int launch_8p_n128(const GemmParams& p, hipStream_t stream) {
+  const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
+  const int v_end = p.tile_end > 0 ? p.tile_end : nbm * nbn;
+  dim3 grid((unsigned)(2 * (v_end - p.tile_begin))), block(512);
+  constexpr int SMEM = LD_LDS_TOTAL;
+  switch (pick_epilogue(p)) {
+    case EPI_QKV: return launch_kernel<ld_gemm8p_n128_kernel<EPI_QKV>>("ld_gemm_qkv_heads(half tiles)", grid, block, SMEM, stream, p);
+    case EPI_BIAS: return launch_kernel<ld_gemm8p_n128_kernel<EPI_BIAS>>("ld_gemm8p_n128", grid, block, SMEM, stream, p);
+    case EPI_GELU: return launch_kernel<ld_gemm8p_n128_kernel<EPI_GELU>>("ld_gemm8p_n128", grid, block, SMEM, stream, p);
+    case EPI_GATE: return launch_kernel<ld_gemm8p_n128_kernel<EPI_GATE>>("ld_gemm8p_n128", grid, block, SMEM, stream, p);
+    default: return launch_kernel<ld_gemm8p_n128_kernel<EPI_GENERIC>>("ld_gemm8p_n128", grid, block, SMEM, stream, p);
   }
 }
 
@@ -1753,6 +2004,19 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = fa
   const long tiles = (long)nbm * nbn;
   const int ncu = 256;
   const long full = tiles / ncu, rem = tiles % ncu;
+  // Round 5: at most half a round left over -> the whole rounds (tiles [0, full * ncu) of the raster, exactly `full` per CU) on the
+  // 8-phase kernel, the rest cut in two along N: 2 * rem <= ncu half tiles, one per CU (ld_gemm8p_n128_kernel).  LD_GEMM_MSPLIT=2:
+  // the round-1..4 form below for every remainder (A/B timing).
+  const bool main_is_8p = (cfg == 8 || use8p) && cfg != 11;
+  if (split == 1 && !conv && main_is_8p && p.m_begin == 0 && full >= 2 && rem > 0 && 2 * rem <= ncu && p.K % BK == 0) {
+    GemmParams a = p, b = p;
+    a.tile_begin = 0; a.tile_end = (int)(full * ncu);
+    b.tile_begin = (int)(full * ncu); b.tile_end = 0;
+    const int rc = big(a);
+    if (rc || dry_run) return rc;
+    return launch_8p_n128(b, stream);
+  }
+  // (rounds 1-4, and today for remainders between 50 and 60 % of a round) the bottom tile ROWS cut off and run as 128 x 128 tiles
   if (split && !conv && p.m_begin == 0 && full >= 2 && rem > 0 && rem * 100 <= 60 * ncu) {
     const int rows_main = (int)((full * ncu) / nbn);           // whole tile rows that fit in `full` rounds
     if (rows_main > 0 && rows_main < nbm) {

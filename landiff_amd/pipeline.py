@@ -176,7 +176,8 @@ class LanDiffPipeline:
 
     @torch.no_grad()
     def generate_stream(self, inp: PromptInputs, n_chunks: int, prefix_frames: int = 7, want_float: bool = False,
-                        tokens: torch.Tensor | None = None, noises=None, randn_like=torch.randn_like, overlap_decode: bool = True):
+                        tokens: torch.Tensor | None = None, noises=None, randn_like=torch.randn_like, overlap_decode: bool = True,
+                        latents_out: list | None = None):
         """Chunked long-video generation out of the reference's streaming primitives -- the reference ships the pieces
         (yaml :213,231 "fixed_frames: 7 # 49 frames, 13 latent, prefix_length=7"), not the loop:
           * ONE multi-segment AR decode (Semantic1DLM.sample with num_frames = n_seg * segment_length, lm_model.py:278-291,
@@ -187,7 +188,8 @@ class LanDiffPipeline:
             (sampling.py:800-835), conditioned on the semantic-feature window of its 13 latent frames;
           * the new latent frames are decoded against the VAE's causal-conv caches of the previous chunk
             (cp_enc_dec.py:436-466), which stay in HBM.
-        Chunk c is seeded with inp.seed + c.  Returns uint8 frames [4T-3 + (n_chunks-1)*4*new, H, W, 3] (+ fp32 video)."""
+        Chunk c is seeded with inp.seed + c.  Returns uint8 frames [4T-3 + (n_chunks-1)*4*new, H, W, 3] (+ fp32 video).
+        latents_out: a list that receives every chunk's sampled latent [1, T, C, h, w] (fp32 values of the bf16 result), for tests."""
         d, lc = self.cfg.dit, self.cfg.llm
         T, new, n_seg = self.stream_plan(n_chunks, prefix_frames)
         per_seg = self.cfg.tok.num_latent_tokens
@@ -269,6 +271,8 @@ class LanDiffPipeline:
                 z = self.sampler.run(self.dit.step, noise, randn_like=randn_like, prefix=prev[:, T - prefix_frames:],
                                      fixed_frames=prefix_frames)
             prev = z.to(torch.bfloat16).float()              # samples.to(self.dtype) (diffusion_video.py:314)
+            if latents_out is not None:
+                latents_out.append(prev.clone())
             self._t("dit", t0)
             t0 = time.perf_counter()
             lat = prev if c == 0 else prev[:, prefix_frames:]
