@@ -23,8 +23,13 @@ build_lib() {   # $1 = object dir, $2 = output, $3 = extra flags, $4.. = sources
       local extra=""
       case $s in ld_attn_pipe.hip|ld_attn_p16.hip|ld_attn_q64.hip|ld_attn_q128.hip) extra="-fno-slp-vectorize";; esac
       # the forms of the decode step (one launch per operation / chained / one persistent launch) must produce the same bits: no
-      # implicit mul+add fusion, whose outcome depends on the code around an expression (explicit fmaf / dot2 are unaffected)
-      case $s in ld_llm.hip|ld_llm_fused.hip) extra="-ffp-contract=off";; esac
+      # implicit mul+add fusion, whose outcome depends on the code around an expression (explicit fmaf / dot2 are unaffected).
+      # -fno-slp-vectorize (round 5): the vectoriser turns e.g. RoPE's `a*c - b*s` / `a*s + b*c` into v_pk_mul_f32 / v_pk_add_f32 with
+      # op_sel / neg modifiers, and THOSE results were observed to depend, at the level of one fp32 rounding, on what the other waves
+      # of the SIMD do: with the DiT's 64-row attention kernel co-resident (AR decode under the DiT loop: generate_many, the streaming
+      # loop) the prefill's rotated q / k came out one bf16 step off in ~1e-5 .. 1e-3 of the even elements, and the decode sampled
+      # other tokens (tools/llm_race_probe2.py, profiles/r05_llm_packed_f32_under_coresidency.txt).  Scalar v_mul / v_sub / v_add: clean.
+      case $s in ld_llm.hip|ld_llm_fused.hip) extra="-ffp-contract=off -fno-slp-vectorize";; esac
       hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result $extra $flags -c "$s" -o "$o" &
       pids+=($!)
     fi

@@ -456,6 +456,11 @@ __device__ __forceinline__ void attn_q128_body(const AttnParams& p, int force_sa
     __syncthreads();
   }
   if (redo && !LD_Q128_ABLATE) safe_pass();          // (an ablated fast pass fails its window test: time it, do not redo it)
+  // Every LDS-DMA of this workgroup has LANDED before the workgroup ends: the loops above run ahead of the tiles they consume (and,
+  // having no peeled tail, request tiles nobody reads); a wave that ended with buffer_load ... lds in flight would let the data
+  // arrive in LDS that may by then belong to the next workgroup on this CU.  (Round 5: added while hunting the co-residency bug
+  // that turned out to be the packed-fp32 one -- csrc/build.sh -- and kept: it measures at 0 us of a 3.6 ms launch.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if ((LD_Q128_ABLATE & 256) && p.kt_min && tid == 0) {
     unsigned long long* dbg = (unsigned long long*)p.kt_min + (long)blockIdx.x * 2;

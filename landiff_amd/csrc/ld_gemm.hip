@@ -28,6 +28,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// ld_conv_narrow.hip: 3x3x3 convolutions with <= 4 output channels; 1 = not its shape, 0 = launched (or would be: dry_run)
+int ld_conv_narrow_try(const void* in_padded, const void* w, const void* bias, void* out, long ldo, long T, long H, long W, long Cin,
+                       long Cout, long kT, long kH, long kW, bool plain_bias_epilogue, hipStream_t stream, bool dry_run);
+
 namespace {
 
 constexpr int BK = 64;
@@ -2004,11 +2008,16 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = fa
   const long tiles = (long)nbm * nbn;
   const int ncu = 256;
   const long full = tiles / ncu, rem = tiles % ncu;
-  // Round 5: at most half a round left over -> the whole rounds (tiles [0, full * ncu) of the raster, exactly `full` per CU) on the
-  // 8-phase kernel, the rest cut in two along N: 2 * rem <= ncu half tiles, one per CU (ld_gemm8p_n128_kernel).  LD_GEMM_MSPLIT=2:
-  // the round-1..4 form below for every remainder (A/B timing).
+  // Round 5: at most half a round left over and a short K -> the whole rounds (tiles [0, full * ncu) of the raster, exactly `full`
+  // per CU) on the 8-phase kernel, the rest cut in two along N: 2 * rem <= ncu half tiles, one per CU (ld_gemm8p_n128_kernel).
+  // Measured (profiles/r05_gemm_half_tile_tail_ab.txt): a half tile takes 0.86 of a full tile's time -- its phases hold 8 MFMAs
+  // between two barriers instead of 16 and the loop's fixed cost per phase no longer hides behind the partner wave -- so the form
+  // only wins where the tail launch's own fixed costs matter: K <= 2048 (DiT qkv -12 us of 765, dense / 4h +-3 us); at K = 7680
+  // (4h->h) it loses 24 us of 831 to the two-per-CU 128 x 128 tiles and is not used.  LD_GEMM_MSPLIT=2: the round-1..4 form below
+  // for every shape, =3: half tiles for every K (A/B timing).
   const bool main_is_8p = (cfg == 8 || use8p) && cfg != 11;
-  if (split == 1 && !conv && main_is_8p && p.m_begin == 0 && full >= 2 && rem > 0 && 2 * rem <= ncu && p.K % BK == 0) {
+  if ((split == 1 || split == 3) && !conv && main_is_8p && p.m_begin == 0 && full >= 2 && rem > 0 && 2 * rem <= ncu && p.K % BK == 0 &&
+      (p.K <= 2048 || split == 3)) {
     GemmParams a = p, b = p;
     a.tile_begin = 0; a.tile_end = (int)(full * ncu);
     b.tile_begin = (int)(full * ncu); b.tile_end = 0;
@@ -2211,6 +2220,10 @@ LD_API int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int
              "(split the chunk in time)", conv_input_bytes(p));
   int rc = fill_epilogue(p, epi);
   if (rc) return rc;
+  // a handful of output channels (the VAE's conv_out): not a GEMM worth a 128-wide tile -- ld_conv_narrow.hip reads the input once
+  const bool plain = !p.act && !p.mul && !p.resid && !p.gate && !p.add2 && !p.out_f32;
+  rc = ld_conv_narrow_try(in_padded, Wt, p.bias, out, ldo, T, H, W, Cin, Cout, kT, kH, kW, plain, (hipStream_t)stream, false);
+  if (rc <= 0) return rc;
   return launch(p, true, (hipStream_t)stream);
 }
 
@@ -2222,6 +2235,7 @@ LD_API int ld_conv_route(int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t C
   p.H = (int)H; p.W_ = (int)W; p.Hp = (int)(H + kH - 1); p.Wp = (int)(W + kW - 1);
   p.Cin = (int)Cin; p.kH = (int)kH; p.kW = (int)kW;
   if (conv_input_bytes(p) >= CONV_MAX_BYTES) return ld_set_error(LD_ERR_INVALID, "ld_conv_route: padded input beyond 8 GiB");
+  if (ld_conv_narrow_try(nullptr, nullptr, nullptr, nullptr, Cout, T, H, W, Cin, Cout, kT, kH, kW, true, nullptr, true) == 0) return 3;
   g_last_route = -1;
   const int rc = launch(p, true, nullptr, /*dry_run=*/true);
   return rc ? rc : g_last_route;

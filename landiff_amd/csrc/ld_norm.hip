@@ -452,9 +452,12 @@ __global__ __launch_bounds__(256) void ld_gn_stats_kernel(const bf16_t* x, doubl
   const int nsub = cpg >= 8 ? 1 : 8 / cpg;       // groups inside one 8-channel chunk (cpg in {2,4} -> 4, 2)
   float gs[4] = {0.f, 0.f, 0.f, 0.f}, gss[4] = {0.f, 0.f, 0.f, 0.f};
   if (rlane < rstep) {
+    // Round 5: GN_U rows are requested before the first is consumed (the loop used to hold ONE 16-byte load in flight per thread:
+    // 2.4 TB/s); the rows are still accumulated one after the other in row order -- the same sums, bit for bit.
+    constexpr int GN_U = 8;
     const long pend = min(p0 + rows_per_block, P);
-    for (long r = p0 + rlane; r < pend; r += rstep) {
-      const u32x4_t a = *(const u32x4_t*)(x + ((long)f * P + r) * C + chunk * 8);
+    const bf16_t* base = x + (long)f * P * C + chunk * 8;
+    auto accumulate = [&](const u32x4_t a) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(a[e]); v[2 * e + 1] = bf_hi(a[e]); }
@@ -465,7 +468,16 @@ __global__ __launch_bounds__(256) void ld_gn_stats_kernel(const bf16_t* x, doubl
 #pragma unroll
         for (int e = 0; e < 8; ++e) { gs[e / cpg % 4] += v[e]; gss[e / cpg % 4] += v[e] * v[e]; }
       }
+    };
+    long r = p0 + rlane;
+    for (; r + (long)(GN_U - 1) * rstep < pend; r += (long)GN_U * rstep) {
+      u32x4_t a[GN_U];
+#pragma unroll
+      for (int u = 0; u < GN_U; ++u) a[u] = __builtin_nontemporal_load((const u32x4_t*)(base + (r + (long)u * rstep) * C));
+#pragma unroll
+      for (int u = 0; u < GN_U; ++u) accumulate(a[u]);
     }
+    for (; r < pend; r += rstep) accumulate(*(const u32x4_t*)(base + r * C));
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) { part[0][tid][q] = gs[q]; part[1][tid][q] = gss[q]; }
@@ -611,13 +623,10 @@ __global__ __launch_bounds__(256) void ld_gn_apply_rows_kernel(GnApplyParams p) 
   bf16_t* orow = p.out + ((((long)f * Tp + t + p.tpad) * Hp + h + p.hpad) * Wp + p.wpad) * p.C + chunk * 8;
   const bf16_t* zyrow = p.zy ? p.zy + ((long)tz * p.Hz + hz) * p.Wz * p.C + chunk * 8 : nullptr;
   const bf16_t* zbrow = p.zy ? p.zb + ((long)tz * p.Hz + hz) * p.Wz * p.C + chunk * 8 : nullptr;
-  for (int w = tid / chunks; w < p.W; w += wstep) {
-    const u32x4_t a = *(const u32x4_t*)(xrow + (long)w * p.C);
-    u32x4_t yw = (u32x4_t){0u, 0u, 0u, 0u}, zw = yw;
-    if (p.zy) {
-      const int wz = (int)(((long)w * p.Wz) / p.W);
-      yw = *(const u32x4_t*)(zyrow + (long)wz * p.C); zw = *(const u32x4_t*)(zbrow + (long)wz * p.C);
-    }
+  // Round 5: GA_U positions per trip, all of their loads (x from HBM, the two zq rows from L2) requested before the first is
+  // normalised -- the loop used to wait for one 16-byte load at a time.  Element-wise work: the same bits.
+  constexpr int GA_U = 4;
+  auto finish = [&](const u32x4_t a, const u32x4_t yw, const u32x4_t zw, int w) {
     u32x4_t ow;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -627,6 +636,31 @@ __global__ __launch_bounds__(256) void ld_gn_apply_rows_kernel(GnApplyParams p) 
       ow[e] = pack_bf16x2(y);
     }
     *(u32x4_t*)(orow + (long)w * p.C) = ow;
+  };
+  int w = tid / chunks;
+  for (; w + (GA_U - 1) * wstep < p.W; w += GA_U * wstep) {
+    u32x4_t a[GA_U], yw[GA_U], zw[GA_U];
+#pragma unroll
+    for (int u = 0; u < GA_U; ++u) {
+      const int wu = w + u * wstep;
+      a[u] = __builtin_nontemporal_load((const u32x4_t*)(xrow + (long)wu * p.C));
+      yw[u] = zw[u] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (p.zy) {
+        const int wz = (int)(((long)wu * p.Wz) / p.W);
+        yw[u] = *(const u32x4_t*)(zyrow + (long)wz * p.C); zw[u] = *(const u32x4_t*)(zbrow + (long)wz * p.C);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GA_U; ++u) finish(a[u], yw[u], zw[u], w + u * wstep);
+  }
+  for (; w < p.W; w += wstep) {
+    const u32x4_t a = *(const u32x4_t*)(xrow + (long)w * p.C);
+    u32x4_t yw = (u32x4_t){0u, 0u, 0u, 0u}, zw = yw;
+    if (p.zy) {
+      const int wz = (int)(((long)w * p.Wz) / p.W);
+      yw = *(const u32x4_t*)(zyrow + (long)wz * p.C); zw = *(const u32x4_t*)(zbrow + (long)wz * p.C);
+    }
+    finish(a, yw, zw, w);
   }
 }
 

@@ -73,6 +73,38 @@ def test_conv_cl(cuda, kT, kH, kW, T, H, W, Cin, Cout):
     assert _rel(out, ref_cl) < 1e-2
 
 
+@pytest.mark.parametrize("T,H,W,Cout", [(1, 4, 16, 3), (3, 8, 48, 3), (9, 12, 32, 4), (2, 4, 16, 1), (8, 64, 96, 3)])
+def test_conv_narrow_output_route(cuda, monkeypatch, T, H, W, Cout):
+    """3x3x3 convolutions with <= 4 output channels over 128 input channels (the VAE's conv_out) take ld_conv_narrow.hip: a rolling
+    three-frame halo window in LDS, K split over the four waves.  Against torch fp32 and against the implicit-GEMM route
+    (LD_CONV_NARROW=0, re-read per call under LD_TUNING=1): a different summation order, so the two routes agree to the bf16
+    rounding of the output, not bit for bit; the kernel itself repeats exactly; columns past Cout of the output rows stay untouched."""
+    from landiff_amd import _lib, ops
+    Cin = 128
+    assert _lib.load().ld_conv_route(T, H, W, Cin, Cout, 3, 3, 3) == 3
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(1, Cin, T + 2, H, W, generator=g).to(cuda, torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.05).to(cuda, torch.bfloat16)
+    bias = torch.randn(Cout, generator=g).to(cuda, torch.bfloat16)
+    ref = torch.nn.functional.conv3d(x.float(), w.float(), bias.float(), padding=(0, 1, 1))[0].permute(1, 2, 3, 0).reshape(T * H * W, Cout)
+    xp = torch.randn(T + 2, H + 2, W + 2, Cin, generator=g).to(cuda, torch.bfloat16) * 0        # zero border
+    xp[:, 1:1 + H, 1:1 + W] = x[0].permute(1, 2, 3, 0)
+    wcl = w.permute(0, 2, 3, 4, 1).contiguous()
+    buf = torch.full((T * H * W, 8), 7.0, device=cuda, dtype=torch.bfloat16)                       # the VAE's rgb buffer: 8 columns per row
+    out = ops.conv_cl(xp, wcl, T, H, W, bias=bias, out=buf[:, :Cout])
+    assert (buf[:, Cout:] == 7.0).all()
+    assert _rel(out, ref) < 1e-2
+    again = ops.conv_cl(xp, wcl, T, H, W, bias=bias).clone()
+    assert torch.equal(again, out.contiguous())
+    monkeypatch.setenv("LD_CONV_NARROW", "0")
+    gemm_route = ops.conv_cl(xp, wcl, T, H, W, bias=bias)
+    monkeypatch.delenv("LD_CONV_NARROW")
+    d = (out.float() - gemm_route.float()).abs()
+    assert d.max().item() <= 2.0 ** -7 * ref.abs().max().item() and (d > 0).float().mean().item() < 0.2      # at most one bf16 step, on few elements
+    # shapes outside the narrow kernel keep the GEMM route
+    assert _lib.load().ld_conv_route(T, H + 1, W, Cin, Cout, 3, 3, 3) != 3 and _lib.load().ld_conv_route(T, H, W, 256, Cout, 3, 3, 3) != 3
+
+
 @pytest.mark.parametrize("B,N,H,K", [(2, 456, 3, 128), (1, 1000, 2, 192), (2, 4440, 5, 320)])
 def test_gemm_qkv_heads_fused_split(cuda, B, N, H, K):
     """ld_gemm_qkv_heads (qkv Linear with QK-LayerNorm / head split / V transpose in its epilogue) against the two-launch

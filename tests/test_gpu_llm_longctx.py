@@ -146,3 +146,71 @@ def test_llm_two_blocks_full_width_decode_at_real_context_lengths_vs_oracle(cuda
         assert err < max(2 * floor, 2e-2), (S + 2 + it, err, floor)
     print("2-block full-width decode, CFG logits vs fp32 oracle (KV length: err / bf16-oracle floor): "
           + ", ".join(f"{L}: {e:.4f} / {f:.4f}" for L, e, f in rows))
+
+
+def test_decode_is_unaffected_by_attention_launches_sharing_the_gpu(cuda):
+    """Regression test of a round-5 finding (the full-size streaming determinism test tripped over it): the AR decode on a second
+    stream UNDER DiT-sized attention launches (generate_many, the streaming loop) sampled other tokens than the same decode on a
+    quiet GPU -- logits off by up to 2 of 30 from the prefill on.  tools/llm_race_probe2.py traced it to ld_llm_rope_append: the
+    compiler's SLP vectoriser had packed RoPE's two dot products into v_pk_mul_f32 / v_pk_add_f32 with op_sel / neg modifiers, and
+    those came out one fp32 rounding different while the 64-row attention kernel's MFMA waves shared the SIMD (never alone, never
+    beside the GEMM or the plain attention kernel).  ld_llm.hip is built with -fno-slp-vectorize since (csrc/build.sh).  Here: the
+    full-width decoder cut to 4 blocks, one frame's decode on a side stream from a helper thread, quiet and under back-to-back
+    attention launches of the DiT shape -- the CFG logits of every step and the ids must be identical, and so must the attention
+    output."""
+    import threading
+    from landiff_amd import ops
+    from landiff_amd.config import LLMConfig
+    from landiff_amd.llm import LLMRunner
+    from landiff_amd.weights import init_state, llm_spec
+    cfg = dataclasses.replace(LLMConfig(), num_layers=4)
+    run = LLMRunner(init_state(llm_spec(cfg), 9, dtype=torch.bfloat16, device=cuda), cfg, cuda)
+    g = torch.Generator(device=cuda).manual_seed(12)
+    text = torch.randn(64, cfg.text_dim, device=cuda, generator=g)
+    Bq, Hq, N = 2, 30, 17776
+    Npad = (N + 127) // 128 * 128
+    q = torch.zeros(Bq, Hq, Npad, 64, device=cuda, dtype=torch.bfloat16); k = torch.zeros_like(q)
+    vt = torch.zeros(Bq, Hq, 64, Npad, device=cuda, dtype=torch.bfloat16)
+    q[:, :, :N] = torch.randn(Bq, Hq, N, 64, device=cuda, generator=g).to(torch.bfloat16)
+    k[:, :, :N] = torch.randn(Bq, Hq, N, 64, device=cuda, generator=g).to(torch.bfloat16)
+    vt[:, :, :, :N] = torch.randn(Bq, Hq, 64, N, device=cuda, generator=g).to(torch.bfloat16)
+    ao = torch.zeros(Bq, N, Hq * 64, device=cuda, dtype=torch.bfloat16)
+    ops.attn_fwd(q, k, vt, ao, N, N, 0.125)
+    torch.cuda.synchronize()
+    ao_ref = ao.clone()
+    side = torch.cuda.Stream(device=cuda, priority=-1)
+
+    def decode(loaded):
+        log, res, done = [], {}, threading.Event()
+
+        def work():
+            try:
+                torch.cuda.set_device(cuda)
+                with torch.cuda.stream(side):
+                    res["ids"] = run.sample(text, guidance_scale=7.5, seed=42, num_frames=1, logits_log=log, mode="chain").clone()
+                    side.synchronize()
+            except BaseException as e:                       # noqa: BLE001 -- reported by the main thread
+                res["error"] = e
+            done.set()
+        side.wait_stream(torch.cuda.current_stream(cuda))
+        th = threading.Thread(target=work)
+        th.start()
+        n = 0
+        while loaded and not done.is_set():
+            ops.attn_fwd(q, k, vt, ao, N, N, 0.125)
+            n += 1
+            if n % 4 == 0:
+                torch.cuda.current_stream(cuda).synchronize()
+        th.join()
+        torch.cuda.synchronize()
+        if "error" in res:
+            raise res["error"]
+        return res["ids"], torch.cat(log, 0), n
+
+    ids0, log0, _ = decode(False)
+    for rep in range(2):
+        ids, log, n = decode(True)
+        assert n >= 8, n                                      # the decode really ran under attention launches
+        assert torch.equal(log, log0), (rep, int((log != log0).any(dim=1).float().argmax()), (log - log0).abs().max().item())
+        assert torch.equal(ids, ids0), rep
+        assert torch.equal(ao, ao_ref), rep
