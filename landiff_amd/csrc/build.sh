@@ -7,7 +7,7 @@
 set -e
 cd "$(dirname "$0")"
 VARIANT_ONLY="ld_attn_pipe.hip ld_attn_q128.hip ld_llm_fused.hip"
-HDRS="ld_common.h ld_attn.h ld_llm_dev.h ../../include/landiff_hip.h"
+HDRS="ld_common.h ld_attn.h ld_llm_dev.h ../../include/landiff_hip.h build.sh"      # (build.sh: a change of flags rebuilds everything)
 
 build_lib() {   # $1 = object dir, $2 = output, $3 = extra flags, $4.. = sources
   local objdir=$1 out=$2 flags=$3; shift 3

@@ -230,10 +230,11 @@ def test_llm_teacher_forced_logits_and_sampler(cuda, setup):
     #    oracle's preference for its own id is smaller than twice that step's measured logit difference -- flip_audit.py; a
     #    flat random model is the worst case for such flips, and every one of them must be explained.
     n_cmp, flips = audit(step_ids, mfn, dev_logits, ref_logits)
-    agree = (ref_codes.reshape(-1) == codes.cpu()).float().mean().item()
     print(f"tiny LLM ids: {n_cmp - len(flips)} / {n_cmp} equal, {len(flips)} flips, all within the logit-noise margin "
-          f"(largest margin {max([f[3] for f in flips], default=0.0):.4f})")
-    assert n_cmp == n_vis and agree >= 0.8, (n_cmp, agree)
+          f"(largest margin {max([f[3] for f in flips], default=0.0):.4f}); first flip at step {flips[0][0] if flips else None}")
+    # no agreement quota: audit() has accounted for every single flip (a flip it cannot explain fails the test), and the ids that
+    # did not flip are exactly the oracle's
+    assert n_cmp == n_vis and int((ref_codes.reshape(-1) != codes.cpu()).sum()) <= len(flips), (n_cmp, len(flips))
     # unguided decode (cfg=0, the dataclass default): first-step logits equal the oracle's batch-1 prefill
     logu = []
     genu = torch.Generator(device=cuda); genu.manual_seed(2)
@@ -321,8 +322,8 @@ def test_llm_first_frame_conditioning(cuda, setup):
     assert err < max(2 * floor, 2e-2), (err, floor)
     assert torch.equal(ref_codes.reshape(-1)[: c.iframe_len], first)
     n_cmp, flips = audit(step_ids, mfn, dev_logits, ref_logits)          # every id flip explained by that step's logit difference
-    agree = (ref_codes.reshape(-1) == codes.cpu()).float().mean().item()
-    assert n_cmp == n_vis - c.iframe_len and agree >= 0.8, (n_cmp, agree, len(flips))
+    print(f"first-frame conditioning: {n_cmp - len(flips)} / {n_cmp} ids equal, first flip at step {flips[0][0] if flips else None}")
+    assert n_cmp == n_vis - c.iframe_len and int((ref_codes.reshape(-1) != codes.cpu()).sum()) <= len(flips), (n_cmp, len(flips))
 
 
 def test_llm_native_step_equals_per_op_step(cuda, setup):
