@@ -207,6 +207,38 @@ def test_dit_multi_layer_step_full_shape_vs_oracle(cuda):
     assert cos > 0.15, cos
 
 
+def test_dit_step_overlapped_equals_serial_at_full_shape(cuda, monkeypatch):
+    """The control / main overlap at the BASELINE shape (4 control + 6 main layers): with LD_DIT_OVERLAP=1 the 64-row attention
+    launches of one chain share the chip -- SIMDs included -- with the other chain's LayerNorm + modulate, GEMM epilogue and gated-
+    residual kernels.  Same launches in another interleaving: two consecutive denoiser evaluations must equal the serial step
+    (LD_DIT_OVERLAP=0) bit for bit, twice.  Tiny-size twin: tests/test_gpu_stages.py.  (Round 5 found packed-fp32 code of the AR decode
+    that did NOT reproduce beside this attention kernel -- DESIGN.md section 5; this is the same question asked of the DiT's own kernels.)"""
+    import dataclasses
+    from landiff_amd.config import PipelineConfig
+    from landiff_amd.dit import ControlDiTRunner
+    from landiff_amd.weights import dit_spec, init_state
+    d = dataclasses.replace(PipelineConfig.full().dit, layers_main=6, layers_control=4)
+    sd_main, sd_ctrl = init_state(dit_spec(d, False), 1), init_state(dit_spec(d, True), 2)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(1, d.latent_frames, d.in_channels, d.latent_h, d.latent_w, generator=g).to(cuda)
+    ctx = torch.randn(1, d.text_len, d.text_dim, generator=g)
+    sem = (0.5 * torch.randn(d.latent_frames, d.in_channels, d.latent_h, d.latent_w, generator=g)).to(torch.bfloat16)
+    outs = []
+    for knob in ("0", "1", "1"):
+        monkeypatch.setenv("LD_DIT_OVERLAP", knob)
+        run = ControlDiTRunner(sd_main, sd_ctrl, d, cuda)
+        assert run.overlap == (knob == "1") and run.fuse_qkv
+        run.set_condition(ctx, sem)
+        o1, o2 = torch.empty_like(x), torch.empty_like(x)
+        run.step(x, 700, -0.6, 0.8, 3.0, o1)
+        run.step(o1, 500, -0.8, 0.6, 5.0, o2)
+        torch.cuda.synchronize()
+        outs.append((o1.clone(), o2.clone()))
+        del run
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+
+
 def test_tokenizer_encoder_full_size_causality(cuda):
     """Full-size encoder (13 x 30 x 45 visual + 1218 latent tokens, 12 layers): the mask's frame causality as a property.
     Changing the features of frames >= f must leave the I tokens (f >= 1) and the P tokens of frames < f bit-identical --
