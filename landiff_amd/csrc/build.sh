@@ -21,7 +21,11 @@ build_lib() {   # $1 = object dir, $2 = output, $3 = extra flags, $4.. = sources
     for h in $HDRS; do [ "$h" -nt "$o" ] && stale=1; done
     if [ $stale = 1 ]; then
       local extra=""
-      case $s in ld_attn_pipe.hip|ld_attn_p16.hip|ld_attn_q64.hip|ld_attn_q128.hip) extra="-fno-slp-vectorize";; esac
+      # -fno-slp-vectorize: (attention files) the vectoriser's packed fp32 ops are an anti-lever beside MFMAs; (ld_norm.hip, ld_llm*.hip,
+      # round 5) it emits v_pk_*_f32 whose LOW lane reads the HIGH register of an operand pair (op_sel) for RoPE-like expressions, and
+      # that operand form reads 0.0 in lanes 48-63 when MFMA waves of another kernel share the SIMD (tools/probe/pk_f32_coresidency.hip).
+      # tools/audit_pk_f32.py checks the BUILT library for the form (a CPU test), whatever the flags of a file are.
+      case $s in ld_attn_pipe.hip|ld_attn_p16.hip|ld_attn_q64.hip|ld_attn_q128.hip|ld_norm.hip) extra="-fno-slp-vectorize";; esac
       # the forms of the decode step (one launch per operation / chained / one persistent launch) must produce the same bits: no
       # implicit mul+add fusion, whose outcome depends on the code around an expression (explicit fmaf / dot2 are unaffected).
       # -fno-slp-vectorize (round 5): the vectoriser turns e.g. RoPE's `a*c - b*s` / `a*s + b*c` into v_pk_mul_f32 / v_pk_add_f32 with
