@@ -52,3 +52,29 @@ def test_streaming_two_chunks_full_size_properties(cuda, fp8):
     frames2 = pipe.generate_stream(inp, chunks, prefix_frames=prefix, latents_out=lat2)
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(lat, lat2)) and torch.equal(frames, frames2)
+
+
+def test_generate_many_full_size_equals_per_prompt_runs(cuda):
+    """The per-rank path of BASELINE configs[3] (a rank that owns several prompts: LanDiffPipeline.generate_many, the AR decode of
+    prompt i + 1 on a second stream under the DiT loop of prompt i) at FULL size, 2 sampler steps: every prompt's frames must be
+    exactly those of a plain per-prompt call.  The tiny-size twin (tests/test_gpu_stages.py) takes the plain attention kernel and never
+    saw what this size does: before round 5 the overlapped decode sampled other tokens here."""
+    from landiff_amd.config import PipelineConfig
+    from landiff_amd.pipeline import LanDiffPipeline, synthetic_inputs
+    from landiff_amd.weights import init_pipeline_state
+    cfg = PipelineConfig.full()
+    cfg = dataclasses.replace(cfg, sampler=dataclasses.replace(cfg.sampler, num_steps=2)).check()
+    states = init_pipeline_state(cfg, seed=1234, dtype=torch.bfloat16, device=cuda)
+    pipe = LanDiffPipeline(cfg, states, cuda)
+    del states
+    torch.cuda.empty_cache()
+    base = synthetic_inputs(cfg, cuda, n_text=64, seed=42)
+    inputs = [dataclasses.replace(base, seed=s) for s in (42, 43, 44)]
+    want = [pipe(inp).clone() for inp in inputs]
+    for rep in range(2):
+        got = pipe.generate_many(inputs)
+        torch.cuda.synchronize()
+        assert len(got) == 3
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (rep, i, (a != b).float().mean().item())
+    assert not torch.equal(want[0], want[1])
