@@ -279,10 +279,12 @@ __device__ __forceinline__ void attn_q64_body(const AttnParams& p, int force_saf
     // ---- the loop: eight halves (four tiles) per trip, over ALL halves rounded up to a multiple of eight.  There is no
     //      peeled tail: halves past the last one (and the keys of the last tile past Nk) are masked to -inf-like scores, i.e.
     //      exactly zero probabilities, their DMA re-fetches the last tile (finite data), and the QK^T issued for the half after
-    //      the last is never used.  At most six extra halves per 2 * n (0.7 % at the DiT shape) instead of 28 peeled iteration
+    //      the last is never used.  At most six extra halves per 2 * n (0.7 % at the DiT shape; since round 5 the last trip ends after four halves when the
+    //      other four hold no key) instead of 28 peeled iteration
     //      bodies whose register pressure spilled (640 MB of scratch writes per launch).  The trips that need no mask run
     //      from a copy of the loop without the mask tests: a uniform branch per half costs the whole step 2.5 %. ----
     const int hmask = p.Nk / 32;                    // first half that holds a key >= Nk
+    const int hend = (p.Nk + 31) / 32;              // first half that holds no key at all
     int hh = 0;
     for (; hh + 8 < hmask; hh += 8) {               // trips that compute no half >= hmask: no mask tests in the instruction stream
       iter(sA, sB, hh,     P0{}, false);
@@ -299,6 +301,10 @@ __device__ __forceinline__ void attn_q64_body(const AttnParams& p, int force_saf
       iter(sB, sA, hh + 1, P1{}, hh + 2 >= hmask);
       iter(sA, sB, hh + 2, P2{}, hh + 3 >= hmask);
       iter(sB, sA, hh + 3, P3{}, hh + 4 >= hmask);
+      if (hh + 4 >= hend) break;                    // round 5: the second half of the last trip holds no key (a period boundary: every
+                                                    // wave agrees, the barrier of period 3 has been passed): at the DiT shape 556 of
+                                                    // the 560 rounded-up halves are left, -0.9 % per launch, the same bits
+                                                    // (profiles/r05_attn_half_trip_exit_ab.txt)
       iter(sA, sB, hh + 4, P4{}, hh + 5 >= hmask);
       iter(sB, sA, hh + 5, P5{}, hh + 6 >= hmask);
       iter(sA, sB, hh + 6, P6{}, hh + 7 >= hmask);
