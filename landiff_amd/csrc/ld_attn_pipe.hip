@@ -309,8 +309,8 @@ __device__ __forceinline__ void attn_pipe2_body(const AttnParams& p, int force_s
     __syncthreads();
   }
   if (redo) ltot = pass(F{});
-  // Every LDS-DMA of this workgroup has LANDED before the workgroup ends: the loops above run ahead of the tiles they consume (and,
-  // having no peeled tail, request tiles nobody reads); a wave that ended with buffer_load ... lds in flight would let the data
+  // Every LDS-DMA of this workgroup has LANDED before the workgroup ends: the loops above run ahead of the tiles they consume;
+  // a wave that ended with buffer_load ... lds in flight would let the data
   // arrive in LDS that may by then belong to the next workgroup on this CU.  (Round 5: added while hunting the co-residency bug
   // that turned out to be the packed-fp32 one -- csrc/build.sh -- and kept: it measures at 0 us of a 3.6 ms launch.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
