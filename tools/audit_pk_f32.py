@@ -23,7 +23,9 @@ RISKY = re.compile(r"v_pk_(?:add|mul|fma)_f32\b.*\bop_sel:\[[01,]*1")
 
 def device_objects(lib, tmp):
     fat = os.path.join(tmp, "fat.bin")
-    subprocess.run(["objcopy", f"--dump-section=.hip_fatbin={fat}", lib], check=True)
+    # (-O binary with an explicit output: `objcopy --dump-section=... lib` without one REWRITES lib in place -- a process that has the
+    #  library mapped, e.g. the test run that called us, then dies of SIGBUS on its next page fault into it)
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
     blob = open(fat, "rb").read()
     starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
     out = []
