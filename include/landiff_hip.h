@@ -25,8 +25,9 @@ extern "C" {
 /* Bumped whenever a signature changes or an entry point is added / removed (2: ld_groupnorm_stats took its `partials`
  * argument, ld_gemm_qkv_heads / ld_llm_sample_advance / ld_groupnorm_stats_blocks / ld_attn_last_kernel were added).  A caller
  * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does).
- * 6: ld_reset and ld_attn_queue_poke were added. */
-#define LD_ABI_VERSION 6
+ * 6: ld_reset and ld_attn_queue_poke were added.  7: ld_conv_cl_bf16_gn, ld_conv_gn_partials_size and
+ * ld_groupnorm_stats_from_conv were added. */
+#define LD_ABI_VERSION 7
 
 int ld_version(void);
 const char* ld_last_error(void);
@@ -90,6 +91,18 @@ int ld_gemm_qkv_heads(const void* A, int64_t lda, const void* W, const void* bia
 int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int64_t ldo,
                     int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                     int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, void* stream);
+
+/* ld_conv_cl_bf16 whose epilogue also leaves GroupNorm partial sums of the bf16 OUTPUT it stores: gn_partials, caller-owned,
+ * ld_conv_gn_partials_size(T*H*W, Cout) floats = [ceil(T*H*W / 64)][Cout / 4][2] (sum, sum of squares of every 64-row x
+ * 4-channel patch), every entry written exactly once by a fixed sequence of fp32 additions (deterministic; no atomics).
+ * ld_groupnorm_stats_from_conv turns them into the statistics ld_groupnorm_stats would compute from a second read of the
+ * activation -- every GroupNorm of the VAE decoder normalises a convolution's output (SpatialNorm3D, cp_enc_dec.py:546-569,
+ * inside the resblock :745-782).  Needs Cout % 8 == 0, ldo % 8 == 0, bf16 output, epilogue operands with leading dimensions
+ * % 8 == 0 (LD_ERR_INVALID otherwise); always the GEMM routes 0-2. */
+int64_t ld_conv_gn_partials_size(int64_t M, int64_t Cout);
+int ld_conv_cl_bf16_gn(const void* in_padded, const void* Wt, void* out, int64_t ldo,
+                       int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                       int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, float* gn_partials, void* stream);
 
 /* Which kernel ld_conv_cl_bf16 runs for a shape, without launching anything (no GPU needed): 0 = 128x128 two-stage,
  * 1 = 256x256 two-stage (32-bit element offsets: padded inputs up to 8 GiB), 2 = 256x256 8-phase (one raw buffer descriptor
@@ -352,6 +365,14 @@ int ld_qkv_split(const void* qkv, void* Q, void* K, void* Vt, int64_t B, int64_t
  * the result is bit-identical from run to run.  stats need not be zeroed. */
 int64_t ld_groupnorm_stats_blocks(int64_t P);
 int ld_groupnorm_stats(const void* x, double* stats, double* partials, int64_t F, int64_t P, int64_t C, int64_t G, void* stream);
+
+/* The same stats[g] (F = 1) from the partial sums ld_conv_cl_bf16_gn left for an output of P rows x C channels: a fold of the
+ * 64-row units into at most 256 double pairs per group (partials: caller-owned workspace of 256 * G * 2 doubles), then the same
+ * fixed-order reduce.  The sums are those of the same bf16 values, added in another order (fp32 within a 64 x 4 patch, double
+ * above): statistics agree with ld_groupnorm_stats to ~1e-7 relative, not bit for bit.  C / 4 a power of two <= 256, G <= 64,
+ * whole quads per group. */
+int ld_groupnorm_stats_from_conv(const float* gn_partials, double* stats, double* partials, int64_t P, int64_t C, int64_t G,
+                                 void* stream);
 
 /* y = swish?( GN(x) [* zy + zb] ) written into the interior of a zero-bordered channels-last buffer
  * [F][T+tpad][H+2*hpad][W+2*wpad][C]; zy/zb [Tz][Hz][Wz][C] are conv_y(zq)/conv_b(zq) at latent resolution, gathered

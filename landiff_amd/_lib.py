@@ -44,7 +44,7 @@ class LlmLayer(Structure):
 
 
 _lib = None
-ABI_VERSION = 6          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
+ABI_VERSION = 7          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
 
 I64 = c_int64
 I32 = c_int32
@@ -57,6 +57,8 @@ SIGNATURES: dict[str, list] = {
     "ld_gemm_bf16": [P, I64, P, P, I64, I64, I64, I64, POINTER(Epilogue), P],
     "ld_gemm_qkv_heads": [P, I64, P, P, I64, I64, P, P, P, I64, I64, I64, I64, P, P, P, P, c_float, P],
     "ld_conv_cl_bf16": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, POINTER(Epilogue), P],
+    "ld_conv_cl_bf16_gn": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, POINTER(Epilogue), P, P],
+    "ld_conv_gn_partials_size": [I64, I64],
     "ld_conv_route": [I64, I64, I64, I64, I64, I64, I64, I64],
     "ld_calib_mfma_bf16": [P, I64, P, I64, I64, POINTER(c_double), P],
     "ld_calib_stream_read": [P, I64, P, P],
@@ -87,6 +89,7 @@ SIGNATURES: dict[str, list] = {
     "ld_qkv_split": [P, P, P, P, I64, I64, I64, I64, I32, P, P, P, P, c_float, P, P, P],
     "ld_groupnorm_stats_blocks": [I64],
     "ld_groupnorm_stats": [P, P, P, I64, I64, I64, I64, P],
+    "ld_groupnorm_stats_from_conv": [P, P, P, I64, I64, I64, P],
     "ld_groupnorm_apply": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I32, c_float, P],
     "ld_patchify": [P, P, P, I64, I64, I64, I64, I64, I64, P],
     "ld_unpatchify_cfg": [P, P, P, I64, I64, I64, I64, I64, c_float, c_float, c_float, P],
@@ -136,7 +139,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = (c_char_p if name in ("ld_last_error", "ld_attn_last_kernel") else
-                      ctypes.c_int64 if name == "ld_groupnorm_stats_blocks" else c_int)
+                      ctypes.c_int64 if name in ("ld_groupnorm_stats_blocks", "ld_conv_gn_partials_size") else c_int)
     _lib = lib
     return lib
 

@@ -73,6 +73,9 @@ struct GemmParams {
   // 8-phase kernels: the launch covers tiles [tile_begin, tile_end) of the 256 x 256 raster (tile_end == 0: all of them).  The
   // whole rounds of the chip go to ld_gemm8p_kernel, the partial last round to ld_gemm8p_n128_kernel as 256 x 128 half tiles.
   int tile_begin, tile_end;
+  // convolutions only: GroupNorm partial statistics of the bf16 output, [ceil(M / 64)][N / 4][2] fp32 = (sum, sum of squares) of
+  // every 64-row x 4-channel patch, written by the epilogue that holds the values anyway (ld_conv_cl_bf16_gn); null: none
+  float* gn_part;
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds_wave_base) {
@@ -185,11 +188,37 @@ enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GATE = 2, EPI_GENERIC = 3, EPI_GELU_MX = 
 // the first row block) and before anything waits on them.  The persistent 8-phase kernel issues the next tile's first K-tile
 // there: LDS-DMA and loads retire in order, so anything the epilogue loads after that would wait for the DMA to land.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int MI, int EPI, typename StageFn, typename Hook = NoHook>
+//
+// GN (the convolution kernels): with p.gn_part set, every lane also sums the FINAL bf16 values it stores -- 8 consecutive channels
+// of 4 rows per 32-row block -- as two 4-channel quads (sum, sum of squares), and after every second row block the 8 lanes that
+// hold the same columns meet in a fixed butterfly and lane 0..7 store the 64-row patch's four numbers.  Each (64-row unit, quad)
+// is written exactly once per launch, by a fixed sequence of fp32 additions: deterministic; ld_gn_stats_from_partials_kernel
+// (ld_norm.hip) sums the units in double in index order.  Replaces the separate read of the whole activation by
+// ld_gn_stats_kernel for the VAE's GroupNorms, all of which normalise a convolution's output (cp_enc_dec.py:546-569, 745-782).
+template <int MI, int EPI, typename StageFn, typename Hook = NoHook, bool GN = false>
 __device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&& stage_block, float* cw, int lane,
                                                    int row0, int col0w, Hook&& hook = Hook{}) {
   const int col0 = (lane & 7) * 8;
   const int gn0 = col0w + col0;
+  static_assert(!GN || (MI % 2 == 0 && (EPI == EPI_BIAS || EPI == EPI_GENERIC)), "GroupNorm partials: 64-row units, conv epilogues");
+  float gq[4] = {0.f, 0.f, 0.f, 0.f};                       // quad 0 (sum, sumsq), quad 1 (sum, sumsq)
+  auto gn_add = [&](const float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gq[0] += v[e]; gq[1] += v[e] * v[e]; }
+#pragma unroll
+    for (int e = 4; e < 8; ++e) { gq[2] += v[e]; gq[3] += v[e] * v[e]; }
+  };
+  auto gn_flush = [&](int unit_row0) {                       // all 64 lanes get here together
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a = gq[q];
+      a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      gq[q] = a;
+    }
+    if (lane < 8 && gn0 < p.N && unit_row0 < p.M)
+      *(f32x4_t*)(p.gn_part + ((long)(unit_row0 >> 6) * (p.N >> 2) + (gn0 >> 2)) * 2) = (f32x4_t){gq[0], gq[1], gq[2], gq[3]};
+    gq[0] = gq[1] = gq[2] = gq[3] = 0.f;
+  };
   if constexpr (EPI == EPI_GENERIC) {
     hook();
     const bool vec_ok = ((p.N & 7) == 0) && ((p.ldo & 7) == 0) &&
@@ -210,8 +239,10 @@ __device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
           epilogue_store8(p, v, gm, gn0, vec_ok);
+          if constexpr (GN) if (p.gn_part) gn_add(v);       // vec_ok (the launcher checks): v holds the stored, rounded values
         }
       }
+      if constexpr (GN && (i & 1)) if (p.gn_part) gn_flush(row0 + (i - 1) * 32);
     };
     row_block(std::integral_constant<int, 0>{});
     if constexpr (MI > 1) row_block(std::integral_constant<int, 1>{});
@@ -307,8 +338,10 @@ __device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&
 #pragma unroll
           for (int e = 0; e < 4; ++e) ow[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
           __builtin_nontemporal_store(ow, (u32x4_t*)((bf16_t*)p.out + (long)gm * p.ldo + gn0));
+          if constexpr (GN) if (p.gn_part) gn_add(v);       // EPI_BIAS: v = rbf2(acc + bias), already the stored values
         }
       }
+      if constexpr (GN && (i & 1)) if (p.gn_part) gn_flush(row0 + (i - 1) * 32);
     };
     // explicit expansion: a `#pragma unroll` over a body this large is silently dropped and acc[] lands in scratch
     row_block(std::integral_constant<int, 0>{});
@@ -319,7 +352,7 @@ __device__ __forceinline__ void gemm_epilogue_core(const GemmParams& p, StageFn&
   static_assert(MI <= 4, "extend the expansion");
 }
 
-template <int MI, int NI, int EPI>
+template <int MI, int NI, int EPI, bool GN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], char* smem, int wave, int lane,
                                               int row0, int col0w) {
   float* cw = (float*)smem + wave * (32 * CW_STRIDE);
@@ -333,7 +366,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         cw[row * CW_STRIDE + j * 32 + (lane & 31)] = acc[i][j][r];
       }
   };
-  gemm_epilogue_core<MI, EPI>(p, stage_block, cw, lane, row0, col0w);
+  gemm_epilogue_core<MI, EPI, decltype(stage_block)&, NoHook, GN>(p, stage_block, cw, lane, row0, col0w);
 }
 
 // Accumulators of v_mfma_f32_16x16x32_bf16: acc[i][j][r] = C[i * 16 + (lane >> 4) * 4 + r][j * 16 + (lane & 15)], a wave tile of
@@ -343,7 +376,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
 // -- a lane's four registers are four consecutive COLUMNS of one row, so staging a block is ONE ds_write_b128 per lane instead of
 // four ds_write_b32 (128 -> 32 LDS store instructions per wave tile; conflict-free: the 8 lanes of a store group are 8 rows,
 // 68 dwords apart).  Same dot products, same results.
-template <int MI, int EPI, int NJ, bool SWAP = false, typename Hook = NoHook>
+template <int MI, int EPI, int NJ, bool SWAP = false, typename Hook = NoHook, bool GN = false>
 __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&acc)[2 * MI][NJ], int j0, char* smem, int wave,
                                                 int lane, int row0, int col0w, Hook&& hook = Hook{}) {
   float* cw = (float*)smem + wave * (32 * CW_STRIDE);
@@ -362,7 +395,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&a
         }
       }
   };
-  gemm_epilogue_core<MI, EPI>(p, stage_block, cw, lane, row0, col0w, hook);
+  gemm_epilogue_core<MI, EPI, decltype(stage_block)&, Hook, GN>(p, stage_block, cw, lane, row0, col0w, static_cast<Hook&&>(hook));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -728,8 +761,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
   if constexpr (EPI == EPI_QKV) {
     static_assert(M16 || EPI != EPI_QKV, "the fused qkv split exists for the 16x16x32 accumulator layout only");
     if constexpr (M16) qkv_epilogue16<MI>(p, acc16, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
-  } else if constexpr (M16) gemm_epilogue16<MI, EPI>(p, acc16, 0, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
-  else gemm_epilogue<MI, NI, EPI>(p, acc, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
+  } else if constexpr (M16) gemm_epilogue16<MI, EPI, 4, false, NoHook, CONV && MI % 2 == 0>(p, acc16, 0, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
+  else gemm_epilogue<MI, NI, EPI, CONV && MI % 2 == 0>(p, acc, smem, wave, lane, m0 + wr * (BM / WM), n0 + wc * 64);
 }
 
 // Two 1 KB LDS-DMA pieces of a half-tile through a raw buffer descriptor (rebuilt from its scalars at every use: loop-invariant
@@ -1023,7 +1056,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
       hooked = true;
     };
     if constexpr (EPI == EPI_QKV) qkv_epilogue16<4>(p, acc, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
-    else gemm_epilogue16<4, EPI, 4, SWAPACC>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
+    else gemm_epilogue16<4, EPI, 4, SWAPACC, decltype(hook)&, CONV>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
     hook();
 #ifdef LD_GEMM_TRACE
     if (tid == 0 && g_gemm_trace) {
@@ -2203,9 +2236,8 @@ LD_API int ld_gemm_qkv_heads(const void* A, int64_t lda, const void* W, const vo
   return launch(p, false, (hipStream_t)stream);
 }
 
-LD_API int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int64_t ldo,
-                           int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
-                           int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, void* stream) {
+static int conv_cl(const void* in_padded, const void* Wt, void* out, int64_t ldo, int64_t T, int64_t H, int64_t W, int64_t Cin,
+                   int64_t Cout, int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, float* gn_partials, void* stream) {
   LD_REQUIRE(in_padded && Wt && out, "ld_conv_cl_bf16: null pointer");
   LD_REQUIRE(T > 0 && H > 0 && W > 0 && Cout > 0, "ld_conv_cl_bf16: empty problem");
   LD_REQUIRE(Cin % BK == 0, "ld_conv_cl_bf16: Cin=%ld must be a multiple of %d (zero-pad channels)", (long)Cin, BK);
@@ -2222,9 +2254,32 @@ LD_API int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int
   if (rc) return rc;
   // a handful of output channels (the VAE's conv_out): not a GEMM worth a 128-wide tile -- ld_conv_narrow.hip reads the input once
   const bool plain = !p.act && !p.mul && !p.resid && !p.gate && !p.add2 && !p.out_f32;
-  rc = ld_conv_narrow_try(in_padded, Wt, p.bias, out, ldo, T, H, W, Cin, Cout, kT, kH, kW, plain, (hipStream_t)stream, false);
-  if (rc <= 0) return rc;
+  if (gn_partials) {
+    // the epilogue sums the values it stores: 16-byte rows of 8 channels only (the vector path of both conv epilogues)
+    LD_REQUIRE(Cout % 8 == 0 && ldo % 8 == 0 && !p.out_f32 && (!p.resid || p.ldr % 8 == 0) && (!p.mul || p.ldmul % 8 == 0) &&
+               (!p.add2 || p.ldadd % 8 == 0), "ld_conv_cl_bf16_gn: Cout, ldo and the epilogue operands' leading dimensions must be multiples of 8, bf16 output");
+    LD_REQUIRE(((uintptr_t)gn_partials & 15) == 0, "ld_conv_cl_bf16_gn: gn_partials must be 16-byte aligned");
+    p.gn_part = gn_partials;
+  } else {
+    rc = ld_conv_narrow_try(in_padded, Wt, p.bias, out, ldo, T, H, W, Cin, Cout, kT, kH, kW, plain, (hipStream_t)stream, false);
+    if (rc <= 0) return rc;
+  }
   return launch(p, true, (hipStream_t)stream);
+}
+
+LD_API int ld_conv_cl_bf16(const void* in_padded, const void* Wt, void* out, int64_t ldo,
+                           int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                           int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, void* stream) {
+  return conv_cl(in_padded, Wt, out, ldo, T, H, W, Cin, Cout, kT, kH, kW, epi, nullptr, stream);
+}
+
+LD_API int64_t ld_conv_gn_partials_size(int64_t M, int64_t Cout) { return ((M + 63) / 64) * (Cout / 4) * 2; }
+
+LD_API int ld_conv_cl_bf16_gn(const void* in_padded, const void* Wt, void* out, int64_t ldo,
+                              int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                              int64_t kT, int64_t kH, int64_t kW, const ld_epilogue_t* epi, float* gn_partials, void* stream) {
+  LD_REQUIRE(gn_partials, "ld_conv_cl_bf16_gn: null gn_partials");
+  return conv_cl(in_padded, Wt, out, ldo, T, H, W, Cin, Cout, kT, kH, kW, epi, gn_partials, stream);
 }
 
 LD_API int ld_conv_route(int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t kT, int64_t kH, int64_t kW) {

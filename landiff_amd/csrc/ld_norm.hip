@@ -435,6 +435,7 @@ __global__ __launch_bounds__(256) void ld_qkv_split_kernel(SplitParams p) {
 // whole VAE / upsampler decode -- are bit-identical from run to run.
 // ---------------------------------------------------------------------------------------------
 constexpr int GN_ROWS_PER_BLOCK = 512;
+constexpr int LD_GN_FOLD_BLOCKS = 256;          // ld_groupnorm_stats_from_conv: workgroups of the fold = double pairs per group in `partials`
 
 __global__ __launch_bounds__(256) void ld_gn_stats_kernel(const bf16_t* x, double* partials, long P, int C, int G, int rows_per_block) {
   // Per-thread partials are combined in a FIXED order: the fp32 LDS atomics this replaced made the statistics differ by
@@ -509,6 +510,32 @@ __global__ __launch_bounds__(64) void ld_gn_stats_reduce_kernel(const double* pa
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
   if (lane == 0) { stats[(long)fg * 2] = s; stats[(long)fg * 2 + 1] = ss; }
+}
+
+// The same statistics from what the producing convolution's epilogue left behind (ld_conv_cl_bf16_gn, ld_gemm.hip): fp32
+// (sum, sum of squares) of every 64-row x 4-channel patch, part [U][C / 4][2].  Workgroup b folds units [b * upb, (b + 1) * upb)
+// into double partials [nblk][G][2] -- thread = (row lane, quad), coalesced rows of C / 4 pairs, row lanes and quads summed in
+// index order -- and ld_gn_stats_reduce_kernel finishes as above.  11 MB instead of the 708 MB activation at 8 x 480 x 720 x 128.
+__global__ __launch_bounds__(256) void ld_gn_fold_partials_kernel(const float* part, double* partials, int U, int C4, int G, int upb) {
+  __shared__ double sh[2][256];
+  const int tid = threadIdx.x;
+  const int quad = tid % C4, ul = tid / C4, ustep = 256 / C4;
+  const int u1 = min((int)(blockIdx.x + 1) * upb, U);
+  double s = 0.0, ss = 0.0;
+  for (int u = blockIdx.x * upb + ul; u < u1; u += ustep) {
+    const ld_f32x2_t v = *(const ld_f32x2_t*)(part + ((long)u * C4 + quad) * 2);
+    s += (double)v[0]; ss += (double)v[1];
+  }
+  sh[0][tid] = s; sh[1][tid] = ss;
+  __syncthreads();
+  if (tid < G) {
+    const int qpg = C4 / G;                                 // quads per group
+    double a = 0.0, b = 0.0;
+    for (int l = 0; l < ustep; ++l)
+      for (int q = tid * qpg; q < (tid + 1) * qpg; ++q) { a += sh[0][l * C4 + q]; b += sh[1][l * C4 + q]; }
+    double* o = partials + ((long)blockIdx.x * G + tid) * 2;
+    o[0] = a; o[1] = b;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -730,6 +757,22 @@ LD_API int ld_groupnorm_stats(const void* x, double* stats, double* partials, in
   hipLaunchKernelGGL(ld_gn_stats_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, partials, (long)P, (int)C, (int)G, rows_per_block);
   hipLaunchKernelGGL(ld_gn_stats_reduce_kernel, dim3((unsigned)(F * G)), dim3(64), 0, (hipStream_t)stream, (const double*)partials, stats, nblk, (int)G);
   return ld_check_launch("ld_groupnorm_stats");
+}
+
+LD_API int ld_groupnorm_stats_from_conv(const float* gn_partials, double* stats, double* partials, int64_t P, int64_t C, int64_t G,
+                                        void* stream) {
+  LD_REQUIRE(gn_partials && stats && partials, "ld_groupnorm_stats_from_conv: null pointer");
+  LD_REQUIRE(P > 0 && P < (1LL << 31) && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0 && G > 0 && G <= 64 && (C / 4) % G == 0,
+             "ld_groupnorm_stats_from_conv: unsupported P=%ld C=%ld G=%ld (C / 4 a power of two <= 256, whole quads per group)", (long)P,
+             (long)C, (long)G);
+  const int U = (int)((P + 63) / 64), C4 = (int)(C / 4);
+  const int rows_at_once = 256 / C4;
+  int upb = (U + LD_GN_FOLD_BLOCKS - 1) / LD_GN_FOLD_BLOCKS;                          // at most LD_GN_FOLD_BLOCKS workgroups ...
+  upb = ((upb + rows_at_once - 1) / rows_at_once) * rows_at_once;                      // ... of whole trips
+  const int nblk = (U + upb - 1) / upb;
+  hipLaunchKernelGGL(ld_gn_fold_partials_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, gn_partials, partials, U, C4, (int)G, upb);
+  hipLaunchKernelGGL(ld_gn_stats_reduce_kernel, dim3((unsigned)G), dim3(64), 0, (hipStream_t)stream, (const double*)partials, stats, nblk, (int)G);
+  return ld_check_launch("ld_groupnorm_stats_from_conv");
 }
 
 LD_API int ld_groupnorm_apply(const void* x, void* out_padded, const double* stats, const void* gamma, const void* beta,

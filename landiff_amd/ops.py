@@ -159,8 +159,10 @@ def gemm_mxfp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.T
 
 
 def conv_cl(x_padded: torch.Tensor, w: torch.Tensor, T: int, H: int, W: int,
-            out: torch.Tensor | None = None, **epi) -> torch.Tensor:
-    """Channels-last conv.  x_padded [T+kT-1, H+kH-1, W+kW-1, Cin]; w [Cout, kT, kH, kW, Cin]."""
+            out: torch.Tensor | None = None, gn_partials: bool = False, **epi):
+    """Channels-last conv.  x_padded [T+kT-1, H+kH-1, W+kW-1, Cin]; w [Cout, kT, kH, kW, Cin].
+    gn_partials=True: returns (out, partials) -- the epilogue also leaves the GroupNorm partial sums of the bf16 output
+    (fp32 [ceil(M / 64)][Cout / 4][2]) for groupnorm_stats_from_conv, instead of a second read of the activation."""
     _bf16(x_padded, "x_padded"); _bf16(w, "w")
     assert x_padded.is_contiguous() and w.is_contiguous() and w.dim() == 5
     Cout, kT, kH, kW, Cin = w.shape
@@ -172,6 +174,11 @@ def conv_cl(x_padded: torch.Tensor, w: torch.Tensor, T: int, H: int, W: int,
     assert out.stride(-1) == 1
     e = make_epilogue(**epi)
     lib = _lib.load()
+    if gn_partials:
+        part = torch.empty(int(lib.ld_conv_gn_partials_size(T * H * W, Cout)), device=x_padded.device, dtype=torch.float32)
+        check(lib.ld_conv_cl_bf16_gn(_ptr(x_padded), _ptr(w), _ptr(out), out.stride(-2), T, H, W, Cin, Cout,
+                                     kT, kH, kW, ctypes.byref(e), _ptr(part), _stream()), "ld_conv_cl_bf16_gn")
+        return out, part
     check(lib.ld_conv_cl_bf16(_ptr(x_padded), _ptr(w), _ptr(out), out.stride(-2), T, H, W, Cin, Cout,
                               kT, kH, kW, ctypes.byref(e), _stream()), "ld_conv_cl_bf16")
     return out
@@ -451,6 +458,19 @@ def groupnorm_stats(x, stats, F, P, C, G):
     lib = _lib.load()
     ws = torch.empty(F * int(lib.ld_groupnorm_stats_blocks(P)) * G * 2, device=stats.device, dtype=torch.float64)
     check(lib.ld_groupnorm_stats(_ptr(x), _ptr(stats), _ptr(ws), F, P, C, G, _stream()), "ld_groupnorm_stats")
+
+
+GN_FOLD_BLOCKS = 256      # ld_norm.hip: LD_GN_FOLD_BLOCKS
+
+
+def groupnorm_stats_from_conv(part, stats, P, C, G):
+    """stats [1, G, 2] float64 <- the partial sums conv_cl(..., gn_partials=True) left behind (P output rows, C channels);
+    deterministic (fixed-order fold + reduce)."""
+    assert stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() == G * 2
+    assert part.dtype == torch.float32 and part.is_contiguous() and part.numel() == (P + 63) // 64 * (C // 4) * 2
+    ws = torch.empty(GN_FOLD_BLOCKS * G * 2, device=stats.device, dtype=torch.float64)
+    check(_lib.load().ld_groupnorm_stats_from_conv(_ptr(part), _ptr(stats), _ptr(ws), P, C, G, _stream()),
+          "ld_groupnorm_stats_from_conv")
 
 
 def groupnorm_apply(x, out_padded, stats, gamma, beta, F, T, H, W, C, G, *, zy=None, zb=None, zshape=(1, 1, 1),

@@ -13,6 +13,8 @@ Differences in mechanism, not in results: the per-conv caches of the last two pa
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -42,11 +44,20 @@ class VAEDecoder:
             else:
                 self.w[k] = _dev(v, device)
         self.cache = {}
+        # GroupNorm statistics from the producing convolution's epilogue (round 5) instead of a pass over the activation;
+        # LD_VAE_GN_FUSE=0: the separate pass (A/B timing; same bf16 values summed in another order)
+        self.fuse_gn_stats = os.environ.get("LD_VAE_GN_FUSE", "1") != "0"
         # Zero-bordered conv-input buffers, one per shape, allocated and zero-filled ONCE: the producing kernels (GroupNorm apply,
         # upsample, latent placement) rewrite the whole interior on every use and the halo frames are refilled from the cache /
         # the first frame, so the spatial borders stay zero.  The decoder is a chain -- a buffer's consumer (the conv) is queued
         # before the next producer of that shape -- so one buffer per shape is enough (stream order is the only hazard).
         self._padded = {}
+
+    def _gn_ok(self, C: int) -> bool:
+        """Can a convolution with C output channels leave GroupNorm partials (whole 4-channel quads per group, ld_conv_cl_bf16_gn)?"""
+        q = C // 4
+        return (self.fuse_gn_stats and C % 8 == 0 and 0 < q <= 256 and 256 % q == 0 and q % self.cfg.gn_groups == 0
+                and self.cfg.gn_groups <= 64)
 
     def _padded_buf(self, *shape):
         buf = self._padded.get(shape)
@@ -57,7 +68,8 @@ class VAEDecoder:
     # ---- building blocks (x is a plain channels-last [T*H*W, C] tensor) ----------------------
     def _causal_conv(self, xp, name, T, H, W, clear, **epi):
         """xp: zero-bordered [T+2][H+2][W+2][C] with the current frames at time offset 2.  Fills the 2-frame
-        halo from the cache (or by replicating the first frame), saves the next cache, runs the conv."""
+        halo from the cache (or by replicating the first frame), saves the next cache, runs the conv.
+        gn_partials=True: returns (out, GroupNorm partial sums of out) -- see _spatial_norm_swish."""
         if name in self.cache:
             xp[:2].copy_(self.cache.pop(name))
         else:
@@ -66,28 +78,39 @@ class VAEDecoder:
             self.cache[name] = xp[T:T + 2].clone()
         return ops.conv_cl(xp, self.w[name + ".conv.weight"], T, H, W, bias=self.w[name + ".conv.bias"], **epi)
 
-    def _spatial_norm_swish(self, x, name, T, H, W, C, zq, zshape, tpad):
-        """swish(GN(x) * conv_y(zq) + conv_b(zq)) -> zero-bordered [T+tpad][H+2][W+2][C]."""
+    def _spatial_norm_swish(self, xg, name, T, H, W, C, zq, zshape, tpad):
+        """swish(GN(x) * conv_y(zq) + conv_b(zq)) -> zero-bordered [T+tpad][H+2][W+2][C].  xg = (x, part): every GroupNorm of this
+        decoder normalises a convolution's output, and the convolution's epilogue has already summed it (part: fp32 sums per
+        64-row x 4-channel patch, ops.conv_cl(gn_partials=True)) -- the statistics cost a fold of those, not a read of x."""
         cfg, dev = self.cfg, self.dev
+        x, part = xg
         zy = ops.gemm(zq, self.w[name + ".conv_y.conv.weight"], bias=self.w[name + ".conv_y.conv.bias"])
         zb = ops.gemm(zq, self.w[name + ".conv_b.conv.weight"], bias=self.w[name + ".conv_b.conv.bias"])
         stats = torch.empty(1, cfg.gn_groups, 2, device=dev, dtype=torch.float64)
-        ops.groupnorm_stats(x, stats, 1, T * H * W, C, cfg.gn_groups)
+        if part is None:
+            ops.groupnorm_stats(x, stats, 1, T * H * W, C, cfg.gn_groups)
+        else:
+            ops.groupnorm_stats_from_conv(part, stats, T * H * W, C, cfg.gn_groups)
         out = self._padded_buf(T + tpad, H + 2, W + 2, C)
         ops.groupnorm_apply(x, out, stats, self.w[name + ".norm_layer.weight"], self.w[name + ".norm_layer.bias"],
                             1, T, H, W, C, cfg.gn_groups, zy=zy, zb=zb, zshape=zshape, tpad=tpad, hpad=1, wpad=1,
                             swish=True, eps=cfg.gn_eps)
         return out
 
-    def _resblock(self, x, p, cin, cout, T, H, W, zq, zshape, clear):
-        hp = self._spatial_norm_swish(x, p + "norm1", T, H, W, cin, zq, zshape, 2)
-        h = self._causal_conv(hp, p + "conv1", T, H, W, clear)
+    def _resblock(self, xg, p, cin, cout, T, H, W, zq, zshape, clear, norm_next=True):
+        """xg = (x, GroupNorm partials of x or None) -> (out, partials of out when a norm consumes it next, else None)."""
+        gn = self._gn_ok(cout)
+        hp = self._spatial_norm_swish(xg, p + "norm1", T, H, W, cin, zq, zshape, 2)
+        hg = self._causal_conv(hp, p + "conv1", T, H, W, clear, gn_partials=gn)
         del hp
-        hp = self._spatial_norm_swish(h, p + "norm2", T, H, W, cout, zq, zshape, 2)
-        del h
+        hp = self._spatial_norm_swish(hg if gn else (hg, None), p + "norm2", T, H, W, cout, zq, zshape, 2)
+        del hg
+        x = xg[0]
         if cin != cout:
             x = ops.gemm(x, self.w[p + "nin_shortcut.weight"], bias=self.w[p + "nin_shortcut.bias"])
-        return self._causal_conv(hp, p + "conv2", T, H, W, clear, resid=x)
+        if gn and norm_next:
+            return self._causal_conv(hp, p + "conv2", T, H, W, clear, resid=x, gn_partials=True)
+        return self._causal_conv(hp, p + "conv2", T, H, W, clear, resid=x), None
 
     def _upsample(self, x, name, T, H, W, C, time_up):
         To = T
@@ -95,8 +118,9 @@ class VAEDecoder:
             To = 1 + 2 * (T - 1) if T % 2 == 1 else 2 * T
         xp = self._padded_buf(To, 2 * H + 2, 2 * W + 2, C)
         ops.place_cl(x, xp, 1, T, H, W, C, C, mode=1, time_up=time_up)
-        out = ops.conv_cl(xp, self.w[name + ".conv.weight"], To, 2 * H, 2 * W, bias=self.w[name + ".conv.bias"])
-        return out, To, 2 * H, 2 * W
+        out = ops.conv_cl(xp, self.w[name + ".conv.weight"], To, 2 * H, 2 * W, bias=self.w[name + ".conv.bias"],
+                          gn_partials=self._gn_ok(C))
+        return (out if self._gn_ok(C) else (out, None)), To, 2 * H, 2 * W
 
     # ---- one chunk ---------------------------------------------------------------------------
     def decode_chunk(self, z_cl: torch.Tensor, T: int, H: int, W: int, clear: bool) -> tuple:
@@ -107,17 +131,22 @@ class VAEDecoder:
         p = "decoder."
         xp = self._padded_buf(T + 2, H + 2, W + 2, ZQ_PAD)
         ops.place_cl(z_cl, xp, 1, T, H, W, ZQ_PAD, ZQ_PAD, mode=0, tpad=2)
-        h = self._causal_conv(xp, p + "conv_in", T, H, W, clear)
-        top = h.shape[1]
+        gn = self._gn_ok(self.w[p + "conv_in.conv.bias"].numel())
+        h = self._causal_conv(xp, p + "conv_in", T, H, W, clear, gn_partials=gn)       # h: (activation, GroupNorm partials | None)
+        if not gn:
+            h = (h, None)
+        top = h[0].shape[1]
         h = self._resblock(h, p + "mid.block_1.", top, top, T, H, W, z_cl, zshape, clear)
         h = self._resblock(h, p + "mid.block_2.", top, top, T, H, W, z_cl, zshape, clear)
         ch = top
         for lvl, blocks, up in vae_levels(cfg):
             for j, (cin, cout) in enumerate(blocks):
-                h = self._resblock(h, p + f"up.{lvl}.block.{j}.", cin, cout, T, H, W, z_cl, zshape, clear)
+                # the last block of a level with an upsampler feeds the placement pass, not a norm
+                h = self._resblock(h, p + f"up.{lvl}.block.{j}.", cin, cout, T, H, W, z_cl, zshape, clear,
+                                   norm_next=not (up and j == len(blocks) - 1))
                 ch = cout
             if up:
-                h, T, H, W = self._upsample(h, p + f"up.{lvl}.upsample", T, H, W, ch, up == "space_time")
+                h, T, H, W = self._upsample(h[0], p + f"up.{lvl}.upsample", T, H, W, ch, up == "space_time")
         hp = self._spatial_norm_swish(h, p + "norm_out", T, H, W, ch, z_cl, zshape, 2)
         del h
         rgb = torch.empty(T * H * W, 8, device=self.dev, dtype=BF)

@@ -105,6 +105,56 @@ def test_conv_narrow_output_route(cuda, monkeypatch, T, H, W, Cout):
     assert _lib.load().ld_conv_route(T, H + 1, W, Cin, Cout, 3, 3, 3) != 3 and _lib.load().ld_conv_route(T, H, W, 256, Cout, 3, 3, 3) != 3
 
 
+@pytest.mark.parametrize("T,H,W,Cin,Cout,route,resid", [(2, 12, 20, 64, 128, 0, True), (1, 8, 8, 64, 512, 0, False),
+                                                         (3, 30, 44, 128, 256, 0, True), (2, 256, 264, 256, 256, 2, True),
+                                                         (2, 256, 264, 256, 256, 2, False)])
+def test_conv_groupnorm_partials(cuda, T, H, W, Cin, Cout, route, resid):
+    """ld_conv_cl_bf16_gn: the convolution's epilogue also sums the bf16 values it stores (per 64-row x 4-channel patch), and
+    ld_groupnorm_stats_from_conv folds those into the GroupNorm statistics -- the VAE's norms no longer read their input twice
+    (cp_enc_dec.py:546-569 inside :745-782).  Output bit-identical to the plain launch; statistics equal to float64 sums over the
+    output (and to ld_groupnorm_stats) to fp32-summation accuracy; repeatable bit for bit.  Shapes: both kernels (128 x 128
+    two-stage, 256 x 256 8-phase), both epilogues (bias / bias + residual), row counts that are not multiples of 64 or of the
+    tile, 4 / 8 / 16 channels per group."""
+    from landiff_amd import _lib, ops
+    assert _lib.load().ld_conv_route(T, H, W, Cin, Cout, 3, 3, 3) == route
+    G, M = 32, T * H * W
+    g = torch.Generator(device="cpu").manual_seed(11)
+    xp = torch.zeros(T + 2, H + 2, W + 2, Cin, device=cuda, dtype=torch.bfloat16)
+    xp[:, 1:1 + H, 1:1 + W] = torch.randn(T + 2, H, W, Cin, generator=g).to(cuda, torch.bfloat16)
+    wcl = (torch.randn(Cout, 3, 3, 3, Cin, generator=g) * 0.03).to(cuda, torch.bfloat16)
+    bias = torch.randn(Cout, generator=g).to(cuda, torch.bfloat16)
+    epi = dict(bias=bias)
+    if resid:
+        epi["resid"] = (torch.randn(M, Cout, generator=g) + 0.5).to(cuda, torch.bfloat16)
+    plain = ops.conv_cl(xp, wcl, T, H, W, **epi)
+    out, part = ops.conv_cl(xp, wcl, T, H, W, gn_partials=True, **epi)
+    assert torch.equal(out, plain)
+    assert part.numel() == (M + 63) // 64 * (Cout // 4) * 2 and torch.isfinite(part).all()
+    stats = torch.full((1, G, 2), float("nan"), device=cuda, dtype=torch.float64)
+    ops.groupnorm_stats_from_conv(part, stats, M, Cout, G)
+    o64 = out.double().view(M, G, Cout // G)
+    want = torch.stack([o64.sum(dim=(0, 2)), (o64 * o64).sum(dim=(0, 2))], dim=-1)
+    scale = torch.stack([o64.abs().sum(dim=(0, 2)), (o64 * o64).sum(dim=(0, 2))], dim=-1)      # the sums' own magnitude (sum of |x|: the mean may cancel)
+    assert ((stats[0] - want).abs() / scale).max().item() < 2e-6
+    old = torch.empty(1, G, 2, device=cuda, dtype=torch.float64)
+    ops.groupnorm_stats(out, old, 1, M, Cout, G)
+    assert ((stats[0] - old[0]).abs() / scale).max().item() < 2e-6
+    # the patch sums themselves, against float64 sums of the same patches
+    U = (M + 63) // 64
+    padded = torch.zeros(U * 64, Cout, device=cuda, dtype=torch.float64)
+    padded[:M] = out.double()
+    p64 = padded.view(U, 64, Cout // 4, 4)
+    want_part = torch.stack([p64.sum(dim=(1, 3)), (p64 * p64).sum(dim=(1, 3))], dim=-1)
+    assert (part.view(U, Cout // 4, 2).double() - want_part).abs().max().item() < 1e-4 * max(1.0, want_part.abs().max().item())
+    out2, part2 = ops.conv_cl(xp, wcl, T, H, W, gn_partials=True, **epi)
+    stats2 = torch.empty_like(stats)
+    ops.groupnorm_stats_from_conv(part2, stats2, M, Cout, G)
+    assert torch.equal(part2, part) and torch.equal(stats2, stats)
+    # refused where the epilogue cannot sum whole 8-channel rows
+    with pytest.raises(Exception):
+        ops.conv_cl(xp, wcl[:12].contiguous(), T, H, W, gn_partials=True, bias=bias[:12].contiguous())
+
+
 @pytest.mark.parametrize("B,N,H,K", [(2, 456, 3, 128), (1, 1000, 2, 192), (2, 4440, 5, 320)])
 def test_gemm_qkv_heads_fused_split(cuda, B, N, H, K):
     """ld_gemm_qkv_heads (qkv Linear with QK-LayerNorm / head split / V transpose in its epilogue) against the two-launch
