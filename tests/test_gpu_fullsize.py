@@ -376,9 +376,11 @@ def test_vae_level0_resblock_full_resolution_vs_oracle(cuda):
     x_cl = x[0].permute(1, 2, 3, 0).reshape(T * H * W, C).contiguous().to(cuda)
     z_cl = torch.zeros(Tz * hz * wz, ZQ_PAD, device=cuda, dtype=torch.bfloat16)
     z_cl[:, : cfg.z_channels] = zq[0].permute(1, 2, 3, 0).reshape(-1, cfg.z_channels).to(cuda)
-    out = dec._resblock(x_cl, p, C, C, T, H, W, z_cl, (Tz, hz, wz), True)
+    # (x, None): norm1 takes its statistics from a pass over x; norm2 from the partial sums conv1's epilogue leaves (round 5)
+    out, part = dec._resblock((x_cl, None), p, C, C, T, H, W, z_cl, (Tz, hz, wz), True)
+    assert dec.fuse_gn_stats and part is not None
     got = out.view(T, H, W, C).permute(3, 0, 1, 2).float().cpu()
-    del dec, out, x_cl
+    del dec, out, x_cl, part
     torch.set_num_threads(min(64, max(torch.get_num_threads(), torch.get_num_threads() * 8)))
     with torch.no_grad():
         ref32 = VAEDecoderOracle(sd, cfg, torch.float32).resblock(x.float(), zq.float(), p, C, C, True)[0]

@@ -1,4 +1,6 @@
-"""Times the full-size VAE decode (13 latent frames 60x90 -> 49 frames 480x720, chunk schedule 3,2,2,2,2,2)."""
+"""Times the full-size VAE decode (13 latent frames 60x90 -> 49 frames 480x720, chunk schedule 3,2,2,2,2,2).
+usage: python tools/vae_time.py [decodes per arm] [ab]   -- `ab`: GroupNorm statistics from the conv epilogues vs the separate
+pass (VAEDecoder.fuse_gn_stats), arms alternated in one process, frames compared."""
 import sys, time, torch
 sys.path.insert(0, ".")
 from landiff_amd.config import PipelineConfig
@@ -12,7 +14,29 @@ d = cfg.dit
 lat = torch.randn(1, d.latent_frames, d.in_channels, d.latent_h, d.latent_w, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
 out = vae.decode(lat); torch.cuda.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-t0 = time.perf_counter()
-for _ in range(n): out = vae.decode(lat)
-torch.cuda.synchronize()
-print(f"VAE decode: {(time.perf_counter() - t0) / n * 1e3:.1f} ms per video, checksum {out.double().sum().item():.3f}")
+
+
+def timed():
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        o = vae.decode(lat)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, o
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "ab":
+    outs = {}
+    for rnd in range(3):
+        for fuse in (True, False):
+            vae.fuse_gn_stats = fuse
+            vae.decode(lat)
+            ms, o = timed()
+            outs[fuse] = o
+            print(f"round {rnd}: GroupNorm statistics {'from the conv epilogues' if fuse else 'as a separate pass   '}: {ms:.1f} ms per video")
+    a, b = outs[True].int(), outs[False].int()
+    diff = (a - b).abs()
+    print(f"frames: {(diff > 0).float().mean().item():.4f} of the uint8 values differ, max {diff.max().item()} grey levels")
+else:
+    ms, out = timed()
+    print(f"VAE decode: {ms:.1f} ms per video, checksum {out.double().sum().item():.3f}")
