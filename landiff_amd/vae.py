@@ -7,7 +7,9 @@ SpatialNorm3D (:546-569), Upsample3D (:605-633), the resblock (:745-782), then _
 (dif_infer.py:37-49) and the uint8 truncation of landiff/utils.py:327-331.
 
 Differences in mechanism, not in results: the per-conv caches of the last two padded input frames stay in HBM
-(the reference bounces them through host memory); activations are [T][H][W][C] so every conv tap is a coalesced
+(the reference bounces them through host memory) -- in place: every causal conv owns a time-linear input buffer of two chunks'
+length, a chunk's producer writes behind the previous chunk's last two frames, and the conv's window simply starts two frames
+earlier (one two-frame copy when the buffer wraps, instead of a copy out and a copy in per conv and chunk); activations are [T][H][W][C] so every conv tap is a coalesced
 128-byte row; conv_y/conv_b of SpatialNorm3D are evaluated at latent resolution and gathered with the nearest rule
 (a 1x1x1 conv commutes with nearest upsampling); GroupNorm statistics stay per chunk, as in the reference.
 """
@@ -43,14 +45,19 @@ class VAEDecoder:
                     self.w[k] = _conv_w(v, device, cin_pad=ZQ_PAD if v.shape[1] < ZQ_PAD else None)
             else:
                 self.w[k] = _dev(v, device)
+        # Causal-conv state (the reference's per-conv cache of the last two padded input frames): conv name -> position of those two
+        # frames in the conv's own input buffer self._win[name] ([R][H+2][W+2][C], R = two chunks + 2 frames; 288 GB of HBM pay
+        # for ~18 GB of such buffers at 480 x 720).  Empty = no state kept (fresh decode / cleared by the last chunk).
         self.cache = {}
+        self._win = {}
+        self._win_pos = {}          # where the window handed out last starts (between _conv_window and _causal_conv)
         # GroupNorm statistics from the producing convolution's epilogue (round 5) instead of a pass over the activation;
         # LD_VAE_GN_FUSE=0: the separate pass (A/B timing; same bf16 values summed in another order)
         self.fuse_gn_stats = os.environ.get("LD_VAE_GN_FUSE", "1") != "0"
-        # Zero-bordered conv-input buffers, one per shape, allocated and zero-filled ONCE: the producing kernels (GroupNorm apply,
-        # upsample, latent placement) rewrite the whole interior on every use and the halo frames are refilled from the cache /
-        # the first frame, so the spatial borders stay zero.  The decoder is a chain -- a buffer's consumer (the conv) is queued
-        # before the next producer of that shape -- so one buffer per shape is enough (stream order is the only hazard).
+        # Zero-bordered inputs of the upsamplers' 2D convs (no time halo, no state), one per shape, allocated and zero-filled
+        # ONCE: the placement kernel rewrites the whole interior on every use, so the spatial borders stay zero; the decoder is
+        # a chain -- a buffer's consumer (the conv) is queued before the next producer of that shape -- so one buffer per shape
+        # is enough (stream order is the only hazard).  The causal convs' inputs live in self._win, zero-filled once the same way.
         self._padded = {}
 
     def _gn_ok(self, C: int) -> bool:
@@ -66,20 +73,39 @@ class VAEDecoder:
         return buf
 
     # ---- building blocks (x is a plain channels-last [T*H*W, C] tensor) ----------------------
+    def _conv_window(self, name, T, H, W, C):
+        """The zero-bordered input window [T+2][H+2][W+2][C] of causal conv `name` for this chunk -- the producer writes the T new
+        frames at time offset 2.  A slice of the conv's own buffer that starts at the previous chunk's last two frames when
+        there was one (self.cache[name]); when the window would run past the end, those two frames move to the front first."""
+        shape = (H + 2, W + 2, C)
+        buf = self._win.get(name)
+        if buf is None or tuple(buf.shape[1:]) != shape or buf.shape[0] < T + 2:
+            assert name not in self.cache, f"{name}: the chunk shape changed under a live cache"
+            buf = self._win[name] = torch.zeros(2 * T + 2, *shape, device=self.dev, dtype=BF)
+        pos = self.cache.get(name, 0)
+        if pos + T + 2 > buf.shape[0]:
+            src = buf[pos:pos + 2]
+            buf[:2].copy_(src if pos >= 2 else src.clone())
+            pos = self.cache[name] = 0
+        self._win_pos[name] = pos
+        return buf[pos:pos + T + 2]
+
     def _causal_conv(self, xp, name, T, H, W, clear, **epi):
-        """xp: zero-bordered [T+2][H+2][W+2][C] with the current frames at time offset 2.  Fills the 2-frame
-        halo from the cache (or by replicating the first frame), saves the next cache, runs the conv.
+        """xp: the window _conv_window(name, ...) with the current frames at time offset 2.  Its first two frames are the
+        previous chunk's last two (already in place) or, on a fresh decode, replicas of the first frame; runs the conv and
+        records where the next chunk's window starts (ContextParallelCausalConv3d.forward(x, clear_cache), cp_enc_dec.py:436-466).
         gn_partials=True: returns (out, GroupNorm partial sums of out) -- see _spatial_norm_swish."""
-        if name in self.cache:
-            xp[:2].copy_(self.cache.pop(name))
-        else:
+        if name not in self.cache:
             xp[0].copy_(xp[2]); xp[1].copy_(xp[2])
-        if not clear:
-            self.cache[name] = xp[T:T + 2].clone()
+        if clear:
+            self.cache.pop(name, None)
+        else:
+            self.cache[name] = self._win_pos[name] + T
         return ops.conv_cl(xp, self.w[name + ".conv.weight"], T, H, W, bias=self.w[name + ".conv.bias"], **epi)
 
-    def _spatial_norm_swish(self, xg, name, T, H, W, C, zq, zshape, tpad):
-        """swish(GN(x) * conv_y(zq) + conv_b(zq)) -> zero-bordered [T+tpad][H+2][W+2][C].  xg = (x, part): every GroupNorm of this
+    def _spatial_norm_swish(self, xg, name, T, H, W, C, zq, zshape, out):
+        """swish(GN(x) * conv_y(zq) + conv_b(zq)) -> the interior of frames 2.. of `out` (zero-bordered [T+2][H+2][W+2][C], the
+        consuming conv's window).  xg = (x, part): every GroupNorm of this
         decoder normalises a convolution's output, and the convolution's epilogue has already summed it (part: fp32 sums per
         64-row x 4-channel patch, ops.conv_cl(gn_partials=True)) -- the statistics cost a fold of those, not a read of x."""
         cfg, dev = self.cfg, self.dev
@@ -91,19 +117,19 @@ class VAEDecoder:
             ops.groupnorm_stats(x, stats, 1, T * H * W, C, cfg.gn_groups)
         else:
             ops.groupnorm_stats_from_conv(part, stats, T * H * W, C, cfg.gn_groups)
-        out = self._padded_buf(T + tpad, H + 2, W + 2, C)
         ops.groupnorm_apply(x, out, stats, self.w[name + ".norm_layer.weight"], self.w[name + ".norm_layer.bias"],
-                            1, T, H, W, C, cfg.gn_groups, zy=zy, zb=zb, zshape=zshape, tpad=tpad, hpad=1, wpad=1,
+                            1, T, H, W, C, cfg.gn_groups, zy=zy, zb=zb, zshape=zshape, tpad=2, hpad=1, wpad=1,
                             swish=True, eps=cfg.gn_eps)
         return out
 
     def _resblock(self, xg, p, cin, cout, T, H, W, zq, zshape, clear, norm_next=True):
         """xg = (x, GroupNorm partials of x or None) -> (out, partials of out when a norm consumes it next, else None)."""
         gn = self._gn_ok(cout)
-        hp = self._spatial_norm_swish(xg, p + "norm1", T, H, W, cin, zq, zshape, 2)
+        hp = self._spatial_norm_swish(xg, p + "norm1", T, H, W, cin, zq, zshape, self._conv_window(p + "conv1", T, H, W, cin))
         hg = self._causal_conv(hp, p + "conv1", T, H, W, clear, gn_partials=gn)
         del hp
-        hp = self._spatial_norm_swish(hg if gn else (hg, None), p + "norm2", T, H, W, cout, zq, zshape, 2)
+        hp = self._spatial_norm_swish(hg if gn else (hg, None), p + "norm2", T, H, W, cout, zq, zshape,
+                                      self._conv_window(p + "conv2", T, H, W, cout))
         del hg
         x = xg[0]
         if cin != cout:
@@ -129,7 +155,7 @@ class VAEDecoder:
         cfg = self.cfg
         zshape = (T, H, W)
         p = "decoder."
-        xp = self._padded_buf(T + 2, H + 2, W + 2, ZQ_PAD)
+        xp = self._conv_window(p + "conv_in", T, H, W, ZQ_PAD)
         ops.place_cl(z_cl, xp, 1, T, H, W, ZQ_PAD, ZQ_PAD, mode=0, tpad=2)
         gn = self._gn_ok(self.w[p + "conv_in.conv.bias"].numel())
         h = self._causal_conv(xp, p + "conv_in", T, H, W, clear, gn_partials=gn)       # h: (activation, GroupNorm partials | None)
@@ -147,7 +173,7 @@ class VAEDecoder:
                 ch = cout
             if up:
                 h, T, H, W = self._upsample(h[0], p + f"up.{lvl}.upsample", T, H, W, ch, up == "space_time")
-        hp = self._spatial_norm_swish(h, p + "norm_out", T, H, W, ch, z_cl, zshape, 2)
+        hp = self._spatial_norm_swish(h, p + "norm_out", T, H, W, ch, z_cl, zshape, self._conv_window(p + "conv_out", T, H, W, ch))
         del h
         rgb = torch.empty(T * H * W, 8, device=self.dev, dtype=BF)
         self._causal_conv(hp, p + "conv_out", T, H, W, clear, out=rgb[:, : cfg.out_ch])
