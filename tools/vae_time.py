@@ -1,8 +1,8 @@
 """Times the full-size VAE decode (13 latent frames 60x90 -> 49 frames 480x720, chunk schedule 3,2,2,2,2,2).
 usage: python tools/vae_time.py [decodes per arm] [ab]   -- `ab`: GroupNorm statistics from the conv epilogues vs the separate
 pass (VAEDecoder.fuse_gn_stats), arms alternated in one process, frames compared."""
-import sys, time, torch
-sys.path.insert(0, ".")
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from landiff_amd.config import PipelineConfig
 from landiff_amd.vae import VAEDecoder
 from landiff_amd.weights import init_pipeline_state
