@@ -13,9 +13,9 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # A test that hangs (a wedged GPU queue, a lost rendezvous) must fail, not stall the whole run: with pytest-timeout present
-    # and no --timeout given, every test gets 15 minutes (the slowest one, the full-size VAE against the fp32 oracle, takes ~4).
+    # and no --timeout given, every test gets 30 minutes (the slowest one, the full-size VAE against the fp32 oracle on the host cores, takes ~4 on an idle host).
     if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
-        config.option.timeout = 900.0
+        config.option.timeout = 1800.0
 
 
 @pytest.fixture(scope="session")
