@@ -44,6 +44,17 @@ def test_argument_validation_without_gpu():
     rc = lib.ld_attn_fwd_bf16(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
                               1, 1, 100, 100, 100, 0, 64, 0.125, None, None, None, None, None)
     assert rc < 0 and b"Npad" in lib.ld_last_error()
+    # the convolution that also leaves GroupNorm partial sums: the workspace size rule, and refusals before any launch
+    assert lib.ld_conv_gn_partials_size(130, 128) == 3 * 32 * 2 and lib.ld_conv_gn_partials_size(64, 512) == 128 * 2
+    p16 = ctypes.c_void_p(16)
+    rc = lib.ld_conv_cl_bf16_gn(p16, p16, p16, 128, 1, 8, 8, 64, 128, 3, 3, 3, None, None, None)
+    assert rc < 0 and b"gn_partials" in lib.ld_last_error()
+    rc = lib.ld_conv_cl_bf16_gn(p16, p16, p16, 12, 1, 8, 8, 64, 12, 3, 3, 3, None, p16, None)          # Cout % 8 != 0
+    assert rc < 0 and b"multiples of 8" in lib.ld_last_error()
+    rc = lib.ld_groupnorm_stats_from_conv(p16, p16, p16, 64, 96, 32, None)                              # C / 4 = 24: not a power of two
+    assert rc < 0 and b"unsupported" in lib.ld_last_error()
+    rc = lib.ld_groupnorm_stats_from_conv(p16, p16, p16, 64, 64, 32, None)                              # half a quad per group
+    assert rc < 0 and b"unsupported" in lib.ld_last_error()
 
 
 def test_conv_route_keeps_large_inputs_off_the_8_phase_kernel():
