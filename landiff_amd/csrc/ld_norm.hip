@@ -553,6 +553,8 @@ struct GnApplyParams {
   int swish;
   float eps;
   double inv_count;
+  int fast_rcp;          // sigmoid's reciprocal as v_rcp_f32 (1 ulp, before the bf16 rounding) instead of the IEEE division sequence
+  int wshift;            // W == Wz << wshift: the nearest-neighbour zq column is a shift (-1: the general rule, a division per position)
 };
 
 __global__ __launch_bounds__(256) void ld_gn_apply_kernel(GnApplyParams p) {
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(256) void ld_gn_apply_kernel(GnApplyParams p) {
       const float bt = (e & 1) ? bf_hi(bw[e >> 1]) : bf_lo(bw[e >> 1]);
       float y = rbf((v[e] - mean) * rstd * gm + bt);      // GroupNorm output (bf16)
       if (p.zy) y = rbf(rbf(y * sy[e]) + sb[e]);                  // norm_f * conv_y(zq) + conv_b(zq)
-      if (p.swish) y = rbf(y * rbf(1.0f / (1.0f + __expf(-y))));  // x * sigmoid(x)
+      if (p.swish) y = rbf(y * rbf(p.fast_rcp ? __builtin_amdgcn_rcpf(1.0f + __expf(-y)) : 1.0f / (1.0f + __expf(-y))));  // x * sigmoid(x)
       v[e] = y;
     }
     const long Tp = p.T + p.tpad, Hp = p.H + 2 * p.hpad, Wp = p.W + 2 * p.wpad;
@@ -659,7 +661,15 @@ __global__ __launch_bounds__(256) void ld_gn_apply_rows_kernel(GnApplyParams p) 
     for (int e = 0; e < 4; ++e) {
       ld_f32x2_t y = rbf2((unpack_bf16x2(a[e]) - mean2[e]) * rstd2[e] * gm2[e] + bt2[e]);      // GroupNorm output (bf16)
       if (p.zy) y = rbf2(rbf2(y * unpack_bf16x2(yw[e])) + unpack_bf16x2(zw[e]));              // norm_f * conv_y(zq) + conv_b(zq)
-      if (p.swish) y = y * rbf2((ld_f32x2_t){1.0f / (1.0f + __expf(-y[0])), 1.0f / (1.0f + __expf(-y[1]))});   // x * sigmoid(x)
+      if (p.swish) {                                                                                     // x * sigmoid(x)
+        const ld_f32x2_t den = {1.0f + __expf(-y[0]), 1.0f + __expf(-y[1])};
+        // Round 5: 1 / den as v_rcp_f32.  The IEEE division the compiler emits for `1.0f / x` is ten VALU instructions, eight times
+        // per 16-byte chunk: together more than the rest of the normalisation, and enough to make this kernel VALU-bound
+        // (3.8 TB/s of read + write at 480 x 720).  The quotient is rounded to bf16 right away; LD_GN_FAST_RCP=0: the division.
+        const ld_f32x2_t sg = p.fast_rcp ? (ld_f32x2_t){__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])}
+                                         : (ld_f32x2_t){1.0f / den[0], 1.0f / den[1]};
+        y = y * rbf2(sg);
+      }
       ow[e] = pack_bf16x2(y);
     }
     *(u32x4_t*)(orow + (long)w * p.C) = ow;
@@ -673,7 +683,7 @@ __global__ __launch_bounds__(256) void ld_gn_apply_rows_kernel(GnApplyParams p) 
       a[u] = __builtin_nontemporal_load((const u32x4_t*)(xrow + (long)wu * p.C));
       yw[u] = zw[u] = (u32x4_t){0u, 0u, 0u, 0u};
       if (p.zy) {
-        const int wz = (int)(((long)wu * p.Wz) / p.W);
+        const int wz = p.wshift >= 0 ? (wu >> p.wshift) : (int)(((long)wu * p.Wz) / p.W);
         yw[u] = *(const u32x4_t*)(zyrow + (long)wz * p.C); zw[u] = *(const u32x4_t*)(zbrow + (long)wz * p.C);
       }
     }
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(256) void ld_gn_apply_rows_kernel(GnApplyParams p) 
     const u32x4_t a = *(const u32x4_t*)(xrow + (long)w * p.C);
     u32x4_t yw = (u32x4_t){0u, 0u, 0u, 0u}, zw = yw;
     if (p.zy) {
-      const int wz = (int)(((long)w * p.Wz) / p.W);
+      const int wz = p.wshift >= 0 ? (w >> p.wshift) : (int)(((long)w * p.Wz) / p.W);
       yw = *(const u32x4_t*)(zyrow + (long)wz * p.C); zw = *(const u32x4_t*)(zbrow + (long)wz * p.C);
     }
     finish(a, yw, zw, w);
@@ -789,6 +799,13 @@ LD_API int ld_groupnorm_apply(const void* x, void* out_padded, const double* sta
   p.F = (int)F; p.T = (int)T; p.H = (int)H; p.W = (int)W; p.C = (int)C; p.G = (int)G;
   p.Tz = (int)Tz; p.Hz = (int)Hz; p.Wz = (int)Wz; p.tpad = (int)tpad; p.hpad = (int)hpad; p.wpad = (int)wpad;
   p.swish = swish; p.eps = eps;
+  static int k_rcp = LD_KNOB_UNSET;
+  p.fast_rcp = ld_knob("LD_GN_FAST_RCP", 1, &k_rcp) != 0;
+  p.wshift = -1;
+  if (zy && Wz > 0 && W % Wz == 0) {
+    const long r = W / Wz;
+    if ((r & (r - 1)) == 0) { p.wshift = 0; while ((1L << p.wshift) < r) ++p.wshift; }
+  }
   p.inv_count = 1.0 / ((double)T * H * W * (C / G));
   const long total = F * T * H * W * (C / 8);
   const long blocks = (total + 255) / 256;
