@@ -2004,8 +2004,12 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = fa
   if (cfg == 0) {
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     // (the DiT's 1920x1920 GEMMs: 256x256 tiles 0.26 ms vs 0.29 ms on 128x128; the VAE's narrow convolutions, Cout <= 512,
-    //  stay on 128x128 tiles unless K is long: 0.50 vs 0.58 s per video)
-    cfg = (tiles256 >= 512 && (conv ? (p.N >= 4096 || p.K >= 4096) : p.K >= 1024)) ? 3 : 1;
+    //  stay on 128x128 tiles unless K is long: 0.50 vs 0.58 s per video.  Round 5, per shape (tools/conv_shape_time.py,
+    //  profiles/r05_vae_conv_route_ab.txt): the 256-wide tile must be at least 3/4 used -- Cin 256 -> Cout 128 at 480 x 720 ran
+    //  with half of its waves dead, 5.82 ms against 4.41 on 128 x 128 tiles -- and K >= 2048 is long enough: the 1 x 3 x 3
+    //  upsampler convs, K = 2304, 3.15 -> 2.69 ms)
+    const bool wide_enough = 4L * p.N >= 3L * 256 * ((p.N + 255) / 256);
+    cfg = (tiles256 >= 512 && (conv ? (wide_enough && p.K >= 2048) : p.K >= 1024)) ? 3 : 1;
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
   if (cfg != 3 && cfg != 11 && cfg != 8) {

@@ -75,6 +75,10 @@ def test_conv_route_keeps_large_inputs_off_the_8_phase_kernel():
     assert lib.ld_conv_route(8, 480, 720, 128, 128, 3, 3, 3) == 0
     assert lib.ld_conv_route(2, 60, 90, 512, 512, 3, 3, 3) == 0
     assert lib.ld_conv_route(2, 60, 90, 100, 512, 3, 3, 3) < 0               # Cin must be a multiple of 64
+    # round 5: a 256-wide tile must be at least 3/4 used (Cout 128 is not: half of its waves would idle), K >= 2048 is long enough
+    assert lib.ld_conv_route(8, 480, 720, 256, 128, 3, 3, 3) == 0
+    assert lib.ld_conv_route(8, 480, 720, 256, 256, 1, 3, 3) == 2 and lib.ld_conv_route(8, 240, 360, 256, 256, 1, 3, 3) == 2
+    assert lib.ld_conv_route(8, 480, 720, 128, 256, 1, 3, 3) == 0            # K = 1152: short
 
 
 def test_decode_step_forms_validate_without_gpu():
