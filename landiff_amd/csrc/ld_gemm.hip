@@ -1076,6 +1076,259 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The 8-phase loop on a 512 x 128 tile (round 5): outputs 128 columns wide (the VAE's Cout = 128 level at 480 x 720: 40 % of its
+// convolution time).  On the 256 x 256 tile such an output leaves the wave columns 2 and 3 -- two of the four SIMDs -- without
+// work; the 128 x 128 two-stage kernel they ran on instead reaches ~1085 TFLOP/s where the 8-phase loop reaches ~1250.  Here the
+// eight waves form 4 wave ROWS x 2 wave columns with the SAME wave tile as ld_gemm8p_kernel (128 x 64, [8][4] accumulators, 16
+// MFMAs per phase) and the same phase schedule, barriers and one-barrier skew between the two waves of a SIMD; what changes is the
+// LDS plan: an A half-tile is 4 x 64 rows (32 KB, four 1 KB LDS-DMA pieces per wave), a W half-tile 2 x 32 columns (8 KB, one
+// piece per wave), a K-tile 80 KB, two of them the whole 160 KB -- so the epilogue staging reuses K-tile buffer 0 behind the
+// barrier that ends the main loop, and a persistent workgroup does not prefetch its next tile's first K-tile (the convolution
+// form of ld_gemm8p_kernel does not either).  The counted wait of ph3 leaves 4 + 1 pieces in flight.  Same dot products in the
+// same order as the other two conv routes: bit-identical outputs.
+// ------------------------------------------------------------------------------------------------
+template <bool CONV, int EPI>
+__global__ __launch_bounds__(512, 2) void ld_gemm8p_m512_kernel(GemmParams p) {
+  static_assert(EPI != EPI_QKV, "the fused qkv split is not built for the 512 x 128 tile");
+  constexpr int BM = 512, BN = 128;
+  constexpr int ASLOT = 256 * 128, BSLOT = 64 * 128;      // A half-tile: 4 wave rows x 64 rows (32 KB); W half-tile: 2 wave columns x 32 (8 KB)
+  constexpr int KBUF = 2 * ASLOT + 2 * BSLOT;             // A0 A1 B0 B1 per K-tile = 80 KB; two buffers = all 160 KB
+  static_assert(2 * KBUF == LD_LDS_TOTAL && 8 * 32 * CW_STRIDE * 4 <= KBUF, "LDS plan");
+  constexpr int EPI_OFF = 0;                              // the epilogue staging reuses K-tile buffer 0 (entered behind a workgroup barrier)
+  constexpr bool SWAPACC = true;                          // C^T accumulator blocks: 16-byte epilogue staging stores (gemm_epilogue16<SWAP>)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wq = wave & 3;                // waves w and w + 4 share a SIMD: they differ in wr only
+  const int wrow = (wq >> 1) * 2 + wr, wc = wq & 1;       // wave row 0..3 (128 tile rows each), wave column 0..1 (64 columns each)
+
+  const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int ntiles = nbm * nbn;
+  const int gm_sz = p.group_m;
+  // virtual block id v -> tile origin (XCD-contiguous logical id -> grouped raster, as ld_gemm_kernel).  gridDim.x is a
+  // multiple of 8 whenever a workgroup owns more than one tile, so v % 8 == blockIdx.x % 8: a workgroup's tiles stay on its XCD.
+  auto tile_origin = [&](int v, int& m0, int& n0) {
+    const int bid = xcd_remap(v, ntiles);
+    const int per_group = gm_sz * nbn;
+    const int group = bid / per_group, in_group = bid - group * per_group;
+    const int first_m = group * gm_sz;
+    const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+    m0 = p.m_begin + (first_m + in_group % rows_here) * BM;
+    n0 = (in_group / rows_here) * BN;
+  };
+
+  // ---- LDS-DMA sources: this wave stages pieces 2 * wave + {0, 1} (8 local rows x 128 B each) of every half-tile ----
+  // Raw buffer descriptors (A: based at the tile's first row, rows past M read as zeros; convolution: the whole padded input,
+  // rows clamped), one 32-bit byte offset per [half][piece] in VGPRs, the K-tile (or filter tap) offset in an SGPR.
+  // (The descriptors are rebuilt from their scalars at every use -- loop-invariant SGPR values for the compiler; a
+  //  __amdgpu_buffer_rsrc_t object captured by nested generic lambdas does not get through the host pass.)
+  const auto clip = [](long v) { return (int)(v < 0x7fffffffL ? v : 0x7fffffffL); };
+  struct Src { const bf16_t* a; const bf16_t* w; int a_bytes, w_bytes; };
+  auto tile_src = [&](int m0, int n0) {
+    Src s;
+    s.a = p.A + (CONV ? 0 : (long)m0 * p.lda);
+    s.w = p.W + (long)n0 * p.K;
+    s.a_bytes = CONV ? 0x7fffffff : clip(((long)(p.M - m0) * p.lda) * 2);
+    s.w_bytes = clip(((long)(p.N - n0) * p.K) * 2);
+    return s;
+  };
+  uint32_t offA[2][4], offW[2];                           // [half][piece] byte offsets: four A pieces and one W piece per half-tile and wave
+  auto set_offsets = [&](int m0, bool weights) {          // (A offsets depend on the tile only for a convolution)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = wave * 32 + i * 8 + (lane >> 3);     // local row of the A slot, 0 .. 255
+      const int chunk = (lane & 7) ^ ((lr >> 1) & 7);     // source-side swizzle (the read applies the same key)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int tm = (lr >> 6) * 128 + h * 64 + (lr & 63);
+        if (CONV) {
+          int gm = m0 + tm; gm = gm < p.M ? gm : p.M - 1;
+          const int hw = p.H * p.W_;
+          const int t = gm / hw, rem = gm - t * hw;
+          const int hh = rem / p.W_, w = rem - hh * p.W_;
+          offA[h][i] = (uint32_t)(((((long)t * p.Hp + hh) * p.Wp + w) * p.Cin + chunk * 8) * 2);
+        } else {
+          offA[h][i] = (uint32_t)(((long)tm * p.lda + chunk * 8) * 2);
+        }
+      }
+    }
+    if (weights) {
+      const int lr = wave * 8 + (lane >> 3);              // local row of the W slot, 0 .. 63
+      const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int tn = (lr >> 5) * 64 + g * 32 + (lr & 31);
+        offW[g] = (uint32_t)(((long)tn * p.K + chunk * 8) * 2);
+      }
+    }
+  };
+  const int nk = p.K / BK;
+  const int cpt = CONV ? p.Cin / BK : 1;
+  auto koff_a = [&](int kt) -> int {                      // byte offset of K-tile kt within an A row
+    if (CONV) {
+      const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+      const int khw = p.kH * p.kW;
+      const int dt = tap / khw, r2 = tap - dt * khw;
+      const int dh = r2 / p.kW, dw = r2 - dh * p.kW;
+      return (int)(((((long)dt * p.Hp + dh) * p.Wp + dw) * p.Cin + c0) * 2);
+    }
+    return kt * (BK * 2);
+  };
+  char* const my_a = smem + wave * 4096;                  // + buffer * KBUF + half * ASLOT (+ 1024 per further piece)
+  char* const my_w = smem + 2 * ASLOT + wave * 1024;      // + buffer * KBUF + half * BSLOT
+  Src src;                                                // the tile being computed
+  auto stage_a = [&](const Src& s, auto bufc, auto hc, int kt) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(hc)::value * ASLOT;
+    const int ko = koff_a(kt);
+    stage_pieces<OFF>(s.a, s.a_bytes, my_a, offA[decltype(hc)::value][0], offA[decltype(hc)::value][1], ko);
+    stage_pieces<OFF + 2048>(s.a, s.a_bytes, my_a, offA[decltype(hc)::value][2], offA[decltype(hc)::value][3], ko);
+  };
+  auto stage_w = [&](const Src& s, auto bufc, auto gc, int kt) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(gc)::value * BSLOT;
+    stage_piece1<OFF>(s.w, s.w_bytes, my_w, offW[decltype(gc)::value], kt * (BK * 2));
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto stage_ktile0 = [&](const Src& s) {
+    stage_a(s, I0{}, I0{}, 0); stage_w(s, I0{}, I0{}, 0); stage_w(s, I0{}, I1{}, 0); stage_a(s, I0{}, I1{}, 0);
+  };
+
+  // fragment reads: 16x16x32 operand = row (lane & 15), 16-byte chunk ks * 4 + (lane >> 4) of the 128-byte K row; the swizzle
+  // key ((row >> 1) & 7) depends on lane & 15 only (block and wave offsets are multiples of 16 rows), so the blocks of a
+  // subtile are immediate offsets (+2048 B) of one address per k-step
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c = (ks * 4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7);
+    rdA[ks] = (wrow * 64 + (lane & 15)) * 128 + (c << 4);
+    rdB[ks] = 2 * ASLOT + (wc * 32 + (lane & 15)) * 128 + (c << 4);
+  }
+  f32x4_t acc[8][4];
+  bf16x8_t a[4][2], b0[2][2], b1[2][2];
+  auto read_a = [&](auto bufc, auto hc) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(hc)::value * ASLOT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[i][ks] = *(const bf16x8_t*)(smem + rdA[ks] + OFF + i * 2048);
+  };
+  auto read_b = [&](auto bufc, auto gc, bf16x8_t (&b)[2][2]) {
+    constexpr int OFF = decltype(bufc)::value * KBUF + decltype(gc)::value * BSLOT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b[j][ks] = *(const bf16x8_t*)(smem + rdB[ks] + OFF + j * 2048);
+  };
+  bool wave_live = true;                                  // (a wave whose 64 columns lie past N issues no MFMAs)
+  auto mma = [&](auto hc, auto gc, bf16x8_t (&b)[2][2]) {
+    constexpr int H = decltype(hc)::value, G = decltype(gc)::value;
+    // lgkmcnt(0) as the BUILTIN (simm16 0xC07F = vmcnt 63, expcnt 7, lgkmcnt 0): hipcc's own wait-count bookkeeping sees it.  As
+    // inline asm it is invisible to that pass, which then re-waits before the next phase's fragment reads on the path that
+    // skips the MFMAs (a pending ds_read into a register it is about to reuse) -- serialising the B and A reads of ph0.
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_live) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[H * 4 + i][G * 2 + j] = SWAPACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0)
+                                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[H * 4 + i][G * 2 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto ktile = [&](auto bufc, int kt) {
+    constexpr int B = decltype(bufc)::value;
+    using Bc = std::integral_constant<int, B>;
+    using Nc = std::integral_constant<int, B ^ 1>;
+    // ph0
+    read_b(Bc{}, I0{}, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(Bc{}, I0{});
+    if (kt + 1 < nk) stage_w(src, Nc{}, I1{}, kt + 1);
+    bar(); mma(I0{}, I0{}, b0); bar();
+    // ph1
+    read_b(Bc{}, I1{}, b1);
+    if (kt + 1 < nk) stage_a(src, Nc{}, I1{}, kt + 1);
+    bar(); mma(I0{}, I1{}, b1); bar();
+    // ph2
+    read_a(Bc{}, I1{});
+    if (kt + 2 < nk) stage_a(src, Bc{}, I0{}, kt + 2);
+    bar(); mma(I1{}, I1{}, b1); bar();
+    // ph3
+    if (kt + 2 < nk) {
+      stage_w(src, Bc{}, I0{}, kt + 2);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // K-tile kt + 1 has landed; A_0 (4 pieces) / B_0 (1) of kt + 2 stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar(); mma(I1{}, I0{}, b0); bar();
+  };
+
+  set_offsets(0, true);
+  bool k0_staged = false;                                 // K-tile 0 of the tile about to start is already on its way
+  const int v_end = p.tile_end > 0 ? p.tile_end : ntiles; // (the tiles behind it: ld_gemm8p_n128_kernel)
+  for (int v = p.tile_begin + blockIdx.x; v < v_end; v += gridDim.x) {
+    int m0, n0;
+    tile_origin(v, m0, n0);
+    src = tile_src(m0, n0);
+    wave_live = n0 + wc * 64 < p.N;
+    if (CONV) set_offsets(m0, false);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: K-tile 0 complete, A_0 / B_0 of K-tile 1 in flight ----
+    if (!k0_staged) stage_ktile0(src);
+    if (nk > 1) {
+      stage_a(src, I1{}, I0{}, 1); stage_w(src, I1{}, I0{}, 1);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    if (wr == 1) bar();                                   // the second wave row runs one barrier behind the first
+
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(I0{}, kt);
+      ktile(I1{}, kt + 1);
+    }
+    if (kt < nk) ktile(I0{}, kt);
+    if (wr == 0) bar();
+    __syncthreads();                                      // every fragment read of this tile has been waited for
+
+    // ---- epilogue, with the next tile's first K-tile requested from inside it ----
+    const int vn = v + gridDim.x;
+    bool hooked = false;
+    Src nsrc = src;
+    k0_staged = false;
+    // (no prefetch of the next tile's first K-tile: the epilogue staging lives in buffer 0)
+    auto hook = [&]() {
+      if (!hooked && k0_staged) stage_ktile0(nsrc);
+      hooked = true;
+    };
+    gemm_epilogue16<4, EPI, 4, SWAPACC, decltype(hook)&, CONV>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wrow * 128, n0 + wc * 64, hook);
+    hook();
+    if (vn < v_end) __syncthreads();                      // the staging region (K-tile buffer 0) is free again before it is re-staged
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // The same 8-phase loop on 256 x 128 HALF tiles (round 5): the partial last round of a launch.  A GEMM whose 256 x 256 tiles
 // do not fill whole rounds of the chip used to send its last tile ROWS to a second launch of 128 x 128 two-stage tiles: two
 // workgroups per CU that share the matrix pipe, 1.4 quarter tiles per CU on average and two on the CUs that set the time -- 9 % of
@@ -1937,6 +2190,20 @@ int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
   }
 }
 
+// 512 x 128 tiles for convolutions with a 128-column output (ld_gemm8p_m512_kernel), persistent like launch_8p
+int launch_8p_m512(const GemmParams& p, hipStream_t stream) {
+  const long ntiles = (long)((p.M + 511) / 512) * ((p.N + 127) / 128);
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0 || (ncu & 7)) ncu = 256;
+  }
+  dim3 grid((unsigned)(ntiles > ncu ? ncu : ntiles)), block(512);
+  if (pick_epilogue(p) == EPI_BIAS) return launch_kernel<ld_gemm8p_m512_kernel<true, EPI_BIAS>>("ld_gemm8p_m512", grid, block, LD_LDS_TOTAL, stream, p);
+  return launch_kernel<ld_gemm8p_m512_kernel<true, EPI_GENERIC>>("ld_gemm8p_m512", grid, block, LD_LDS_TOTAL, stream, p);
+}
+
 // the partial last round of a launch as 256 x 128 half tiles, one per workgroup (ld_gemm8p_n128_kernel)
 int launch_8p_n128(const GemmParams& p, hipStream_t stream) {
   const int nbm = (p.M - p.m_begin + 255) / 256, nbn = (p.N + 255) / 256;
@@ -1978,7 +2245,7 @@ long conv_input_bytes(const GemmParams& p) {
 constexpr long CONV_8P_MAX_BYTES = 0x7fffffffL;
 constexpr long CONV_MAX_BYTES = 1L << 33;
 
-enum { ROUTE_128_2STAGE = 0, ROUTE_256_2STAGE = 1, ROUTE_256_8PHASE = 2, ROUTE_256_W4R = 3 };
+enum { ROUTE_128_2STAGE = 0, ROUTE_256_2STAGE = 1, ROUTE_256_8PHASE = 2, ROUTE_256_W4R = 3, ROUTE_512_8PHASE = 4 };
 thread_local int g_last_route = -1;   // what launch() picked last ON THIS HOST THREAD (ld_conv_route's dry run reads it; the
                                       // pipeline runs launches from a helper thread too)
 
@@ -2012,6 +2279,16 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = fa
     cfg = (tiles256 >= 512 && (conv ? (wide_enough && p.K >= 2048) : p.K >= 1024)) ? 3 : 1;
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
+  // Round 5: a convolution with one 128-wide column of output and a long K (the VAE's 480 x 720 level) takes 512 x 128 tiles on the
+  // 8-phase loop when they fill the chip at least once (LD_GEMM_M512=0: the 128 x 128 two-stage tiles it ran on before).
+  // Measured per shape (profiles/r05_vae_conv_route_ab.txt): Cin 128 (K = 3456) 2.37 -> 2.16 ms per 8 frames; Cin 256 (K = 6912)
+  // 4.49 -> 4.92 ms, so the rule stops at K = 4096 and that shape keeps the 128 x 128 tiles.
+  static int k_m512 = LD_KNOB_UNSET;
+  if (conv && forced == 0 && p.N > 64 && p.N <= 128 && p.K >= 2048 && p.K <= 4096 && p.K % BK == 0 && (p.M + 511) / 512 >= 256 &&
+      conv_input_bytes(p) < CONV_8P_MAX_BYTES && ld_knob("LD_GEMM_M512", 1, &k_m512) != 0) {
+    g_last_route = ROUTE_512_8PHASE;
+    return dry_run ? 0 : launch_8p_m512(p, stream);
+  }
   if (cfg != 3 && cfg != 11 && cfg != 8) {
     g_last_route = ROUTE_128_2STAGE;
     return dry_run ? 0 : launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);
