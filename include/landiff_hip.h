@@ -109,8 +109,9 @@ int ld_conv_cl_bf16_gn(const void* in_padded, const void* Wt, void* out, int64_t
  * over the padded input: inputs below 2 GiB only -- larger ones are routed to 1), negative = the shape is refused
  * (e.g. a padded input of 8 GiB or more), 3 = the narrow-output kernel (3x3x3, Cin 128, <= 4 output channels, H % 4 == 0,
  * W % 16 == 0 and a bias-only epilogue -- the VAE's conv_out: ld_conv_narrow.hip reads the input once instead of once per tap),
- * 4 = 512x128 8-phase (64 < Cout <= 128, 2048 <= K <= 4096, at least 256 such tiles, padded input below 2 GiB: the VAE's 480x720 level).
- * All GEMM routes (0, 1, 2, 4) give bit-identical outputs.  Host logic only; lets the size guard be tested on CPU. */
+ * 4 = 512x128 8-phase (VARIANTS build with LD_GEMM_M512=1 only: 64 < Cout <= 128, 2048 <= K <= 4096, at least 256 such tiles,
+ * padded input below 2 GiB -- a measured alternative for the VAE's 480x720 level).  All GEMM routes (0, 1, 2, 4) give bit-identical
+ * outputs.  Host logic only; lets the size guard be tested on CPU. */
 int ld_conv_route(int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t kT, int64_t kH, int64_t kW);
 
 /* ---- calibration loops for bench.py (not on the product path; ld_calib.hip) ----

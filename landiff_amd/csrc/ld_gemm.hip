@@ -1075,6 +1075,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
   }
 }
 
+#ifdef LD_VARIANTS   // measured alternative, not in the shipped library
 // ------------------------------------------------------------------------------------------------
 // The 8-phase loop on a 512 x 128 tile (round 5): outputs 128 columns wide (the VAE's Cout = 128 level at 480 x 720: 40 % of its
 // convolution time).  On the 256 x 256 tile such an output leaves the wave columns 2 and 3 -- two of the four SIMDs -- without
@@ -1086,6 +1087,10 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
 // barrier that ends the main loop, and a persistent workgroup does not prefetch its next tile's first K-tile (the convolution
 // form of ld_gemm8p_kernel does not either).  The counted wait of ph3 leaves 4 + 1 pieces in flight.  Same dot products in the
 // same order as the other two conv routes: bit-identical outputs.
+// MEASURED (profiles/r05_vae_conv_route_ab.txt): alone in a loop 2.37 -> 2.16 ms per 8-frame launch (1135 vs 1031 TFLOP/s); inside
+// the VAE decode, same box, arms alternated: 337.4 / 336.7 ms per video against 337.4 / 335.7 -- no gain (in context the 128 x 128
+// tiles already run at ~1085) -- so it is a measured alternative of the VARIANTS build (LD_GEMM_M512=1 there), not a shipped route.
+// Its reason to stay under test: the DiT GEMMs' half-empty last tile column.
 // ------------------------------------------------------------------------------------------------
 template <bool CONV, int EPI>
 __global__ __launch_bounds__(512, 2) void ld_gemm8p_m512_kernel(GemmParams p) {
@@ -1327,6 +1332,8 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_m512_kernel(GemmParams p) {
   }
 }
 
+
+#endif  // LD_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
 // The same 8-phase loop on 256 x 128 HALF tiles (round 5): the partial last round of a launch.  A GEMM whose 256 x 256 tiles
@@ -2190,6 +2197,7 @@ int launch_8p(const GemmParams& p, bool conv, hipStream_t stream) {
   }
 }
 
+#ifdef LD_VARIANTS
 // 512 x 128 tiles for convolutions with a 128-column output (ld_gemm8p_m512_kernel), persistent like launch_8p
 int launch_8p_m512(const GemmParams& p, hipStream_t stream) {
   const long ntiles = (long)((p.M + 511) / 512) * ((p.N + 127) / 128);
@@ -2203,6 +2211,7 @@ int launch_8p_m512(const GemmParams& p, hipStream_t stream) {
   if (pick_epilogue(p) == EPI_BIAS) return launch_kernel<ld_gemm8p_m512_kernel<true, EPI_BIAS>>("ld_gemm8p_m512", grid, block, LD_LDS_TOTAL, stream, p);
   return launch_kernel<ld_gemm8p_m512_kernel<true, EPI_GENERIC>>("ld_gemm8p_m512", grid, block, LD_LDS_TOTAL, stream, p);
 }
+#endif  // LD_VARIANTS
 
 // the partial last round of a launch as 256 x 128 half tiles, one per workgroup (ld_gemm8p_n128_kernel)
 int launch_8p_n128(const GemmParams& p, hipStream_t stream) {
@@ -2279,16 +2288,17 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = fa
     cfg = (tiles256 >= 512 && (conv ? (wide_enough && p.K >= 2048) : p.K >= 1024)) ? 3 : 1;
   }
   const bool pp_ok = (p.K % 128 == 0) && (!conv || p.Cin % 32 == 0);
-  // Round 5: a convolution with one 128-wide column of output and a long K (the VAE's 480 x 720 level) takes 512 x 128 tiles on the
-  // 8-phase loop when they fill the chip at least once (LD_GEMM_M512=0: the 128 x 128 two-stage tiles it ran on before).
-  // Measured per shape (profiles/r05_vae_conv_route_ab.txt): Cin 128 (K = 3456) 2.37 -> 2.16 ms per 8 frames; Cin 256 (K = 6912)
-  // 4.49 -> 4.92 ms, so the rule stops at K = 4096 and that shape keeps the 128 x 128 tiles.
+#ifdef LD_VARIANTS
+  // LD_GEMM_M512=1 (variants build): a convolution with one 128-wide column of output and 2048 <= K <= 4096 (the VAE's 480 x 720
+  // level) on 512 x 128 tiles of the 8-phase loop, when they fill the chip at least once.  Bit-identical; faster alone (2.37 ->
+  // 2.16 ms), no gain inside the VAE decode: see ld_gemm8p_m512_kernel.  At K = 6912 (Cin 256) it measured slower: 4.49 -> 4.92 ms.
   static int k_m512 = LD_KNOB_UNSET;
   if (conv && forced == 0 && p.N > 64 && p.N <= 128 && p.K >= 2048 && p.K <= 4096 && p.K % BK == 0 && (p.M + 511) / 512 >= 256 &&
-      conv_input_bytes(p) < CONV_8P_MAX_BYTES && ld_knob("LD_GEMM_M512", 1, &k_m512) != 0) {
+      conv_input_bytes(p) < CONV_8P_MAX_BYTES && ld_knob("LD_GEMM_M512", 0, &k_m512) != 0) {
     g_last_route = ROUTE_512_8PHASE;
     return dry_run ? 0 : launch_8p_m512(p, stream);
   }
+#endif
   if (cfg != 3 && cfg != 11 && cfg != 8) {
     g_last_route = ROUTE_128_2STAGE;
     return dry_run ? 0 : launch_cfg<128, 128, 2, 2, 2>(p, conv, stream);

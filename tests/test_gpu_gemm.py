@@ -105,47 +105,9 @@ def test_conv_narrow_output_route(cuda, monkeypatch, T, H, W, Cout):
     assert _lib.load().ld_conv_route(T, H + 1, W, Cin, Cout, 3, 3, 3) != 3 and _lib.load().ld_conv_route(T, H, W, 256, Cout, 3, 3, 3) != 3
 
 
-@pytest.mark.parametrize("T,H,W,Cin,Cout,resid", [(2, 256, 264, 128, 128, False), (3, 212, 210, 128, 128, True), (2, 256, 260, 128, 96, True),
-                                                   (9, 120, 128, 128, 128, False)])
-def test_conv_512x128_tile_route(cuda, monkeypatch, T, H, W, Cin, Cout, resid):
-    """Convolutions with one 128-wide column of output and K >= 2048 (the VAE's 480 x 720 level) take ld_gemm8p_m512_kernel: the
-    8-phase loop on a 512 x 128 tile, 4 wave rows x 2 wave columns with the wave tile of the 256 x 256 kernel.  Bit-identical to the
-    128 x 128 two-stage route it replaces (LD_GEMM_M512=0, re-read per call under LD_TUNING=1) and within bf16 rounding of torch
-    fp32; row counts that are not multiples of 512, a column count below 128, both epilogues, repeatable."""
-    from landiff_amd import _lib, ops
-    lib = _lib.load()
-    assert lib.ld_conv_route(T, H, W, Cin, Cout, 3, 3, 3) == 4
-    M = T * H * W
-    g = torch.Generator(device="cpu").manual_seed(13)
-    xp = torch.zeros(T + 2, H + 2, W + 2, Cin, device=cuda, dtype=torch.bfloat16)
-    xp[:, 1:1 + H, 1:1 + W] = torch.randn(T + 2, H, W, Cin, generator=g).to(cuda, torch.bfloat16)
-    wcl = (torch.randn(Cout, 3, 3, 3, Cin, generator=g) * 0.03).to(cuda, torch.bfloat16)
-    bias = torch.randn(Cout, generator=g).to(cuda, torch.bfloat16)
-    epi = dict(bias=bias)
-    if resid:
-        epi["resid"] = torch.randn(M, Cout, generator=g).to(cuda, torch.bfloat16)
-    out = ops.conv_cl(xp, wcl, T, H, W, **epi)
-    again = ops.conv_cl(xp, wcl, T, H, W, **epi)
-    assert torch.equal(out, again)
-    monkeypatch.setenv("LD_GEMM_M512", "0")
-    assert lib.ld_conv_route(T, H, W, Cin, Cout, 3, 3, 3) == 0
-    old = ops.conv_cl(xp, wcl, T, H, W, **epi)
-    monkeypatch.delenv("LD_GEMM_M512")
-    assert torch.equal(out, old)
-    # torch fp32 on 4096 output rows (first / last rows of the problem and of tiles included): patches gathered from the padded input
-    rows = torch.cat([torch.arange(0, 1024), torch.arange(M - 1024, M), torch.randint(0, M, (2048,), generator=g)]).to(cuda)
-    t, h, w = rows // (H * W), (rows // W) % H, rows % W
-    patch = torch.stack([xp[t + dt, h + dh, w + dw] for dt in range(3) for dh in range(3) for dw in range(3)], dim=1)      # [n][27][Cin]
-    ref = patch.reshape(len(rows), -1).float() @ wcl.reshape(Cout, -1).float().T + bias.float()
-    if resid:
-        ref = ref.to(torch.bfloat16).float() + epi["resid"][rows].float()
-    assert _rel(out[rows], ref) < 1e-2
-
-
 @pytest.mark.parametrize("T,H,W,Cin,Cout,route,resid", [(2, 12, 20, 64, 128, 0, True), (1, 8, 8, 64, 512, 0, False),
                                                          (3, 30, 44, 128, 256, 0, True), (2, 256, 264, 256, 256, 2, True),
-                                                         (2, 256, 264, 256, 256, 2, False), (2, 256, 264, 128, 128, 4, True),
-                                                         (3, 212, 210, 128, 128, 4, False)])
+                                                         (2, 256, 264, 256, 256, 2, False)])
 def test_conv_groupnorm_partials(cuda, T, H, W, Cin, Cout, route, resid):
     """ld_conv_cl_bf16_gn: the convolution's epilogue also sums the bf16 values it stores (per 64-row x 4-channel patch), and
     ld_groupnorm_stats_from_conv folds those into the GroupNorm statistics -- the VAE's norms no longer read their input twice

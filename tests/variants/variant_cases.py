@@ -1,6 +1,6 @@
 """Tests of the measured alternatives that only the VARIANTS build of the library carries (landiff_amd/csrc/build.sh with
-LD_BUILD_VARIANTS=1 -> landiff_amd/variants/liblandiff_hip_variants.so): the 128-query-row one-wave-per-SIMD attention tile and
-the chained / persistent forms of the decode step.  Not collected by the normal run (the file name does not match test_*.py):
+LD_BUILD_VARIANTS=1 -> landiff_amd/variants/liblandiff_hip_variants.so): the 128-query-row one-wave-per-SIMD attention tile, the
+chained / persistent forms of the decode step and the 512 x 128 tile of the 8-phase GEMM loop.  Not collected by the normal run (the file name does not match test_*.py):
 tests/test_gpu_variants.py::test_variants_build_suite runs this file in a child pytest process with LANDIFF_HIP_LIB pointing
 at the variants library, so that the processes of the normal suite only ever map the shipped library."""
 import os
@@ -121,3 +121,47 @@ def test_llm_full_size_chained_and_fused_blocks_equal_chain(cuda):
             assert torch.equal(u, v), mode
 
 
+# ---- the 512 x 128 tile of the 8-phase GEMM loop for 128-column convolutions (ld_gemm8p_m512_kernel; LD_GEMM_M512 per call) ----
+@pytest.mark.parametrize("T,H,W,Cin,Cout,resid", [(2, 256, 264, 128, 128, False), (3, 212, 210, 128, 128, True), (2, 256, 260, 128, 96, True),
+                                                   (9, 120, 128, 128, 128, False)])
+def test_conv_512x128_tile_route(cuda, monkeypatch, T, H, W, Cin, Cout, resid):
+    """LD_GEMM_M512=1 (variants build): convolutions with one 128-wide column of output and 2048 <= K <= 4096 (the VAE's 480 x 720
+    level) on ld_gemm8p_m512_kernel, the 8-phase loop on a 512 x 128 tile, 4 wave rows x 2 wave columns with the wave tile of the
+    256 x 256 kernel.  Bit-identical to the 128 x 128 two-stage route of the shipped library (the knob is re-read per call under
+    LD_TUNING=1) and within bf16 rounding of torch fp32 on sampled rows; row counts that are not multiples of 512, a column count
+    below 128, both epilogues, GroupNorm partial sums from its epilogue, repeatable."""
+    from landiff_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.ld_conv_route(T, H, W, Cin, Cout, 3, 3, 3) == 0
+    monkeypatch.setenv("LD_GEMM_M512", "1")
+    assert lib.ld_conv_route(T, H, W, Cin, Cout, 3, 3, 3) == 4
+    M = T * H * W
+    g = torch.Generator(device="cpu").manual_seed(13)
+    xp = torch.zeros(T + 2, H + 2, W + 2, Cin, device=cuda, dtype=torch.bfloat16)
+    xp[:, 1:1 + H, 1:1 + W] = torch.randn(T + 2, H, W, Cin, generator=g).to(cuda, torch.bfloat16)
+    wcl = (torch.randn(Cout, 3, 3, 3, Cin, generator=g) * 0.03).to(cuda, torch.bfloat16)
+    bias = torch.randn(Cout, generator=g).to(cuda, torch.bfloat16)
+    epi = dict(bias=bias)
+    if resid:
+        epi["resid"] = torch.randn(M, Cout, generator=g).to(cuda, torch.bfloat16)
+    out = ops.conv_cl(xp, wcl, T, H, W, **epi)
+    again = ops.conv_cl(xp, wcl, T, H, W, **epi)
+    assert torch.equal(out, again)
+    if Cout % 8 == 0:
+        out_g, part = ops.conv_cl(xp, wcl, T, H, W, gn_partials=True, **epi)
+        assert torch.equal(out_g, out)
+    monkeypatch.setenv("LD_GEMM_M512", "0")
+    assert lib.ld_conv_route(T, H, W, Cin, Cout, 3, 3, 3) == 0
+    old = ops.conv_cl(xp, wcl, T, H, W, **epi)
+    assert torch.equal(out, old)
+    if Cout % 8 == 0:
+        _, part_old = ops.conv_cl(xp, wcl, T, H, W, gn_partials=True, **epi)
+        assert torch.equal(part, part_old)                 # the same epilogue on the same 64-row units: the same partial sums
+    # torch fp32 on 4096 output rows (first / last rows of the problem and of tiles included): patches gathered from the padded input
+    rows = torch.cat([torch.arange(0, 1024), torch.arange(M - 1024, M), torch.randint(0, M, (2048,), generator=g)]).to(cuda)
+    t, h, w = rows // (H * W), (rows // W) % H, rows % W
+    patch = torch.stack([xp[t + dt, h + dh, w + dw] for dt in range(3) for dh in range(3) for dw in range(3)], dim=1)      # [n][27][Cin]
+    ref = patch.reshape(len(rows), -1).float() @ wcl.reshape(Cout, -1).float().T + bias.float()
+    if resid:
+        ref = ref.to(torch.bfloat16).float() + epi["resid"][rows].float()
+    assert (out[rows].float() - ref).abs().max().item() / ref.abs().max().item() < 1e-2

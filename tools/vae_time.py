@@ -1,7 +1,7 @@
 """Times the full-size VAE decode (13 latent frames 60x90 -> 49 frames 480x720, chunk schedule 3,2,2,2,2,2).
-usage: python tools/vae_time.py [decodes per arm] [ab | rcp]   -- `ab`: GroupNorm statistics from the conv epilogues vs the
+usage: python tools/vae_time.py [decodes per arm] [ab | rcp | m512]   -- `ab`: GroupNorm statistics from the conv epilogues vs the
 separate pass (VAEDecoder.fuse_gn_stats); `rcp`: the sigmoid's reciprocal in GroupNorm apply as v_rcp_f32 vs the IEEE division
-(LD_GN_FAST_RCP); arms alternated in one process, frames compared."""
+(LD_GN_FAST_RCP); `m512`: the 512 x 128 tile of the 8-phase loop vs the 128 x 128 tiles (LD_GEMM_M512); arms alternated in one process, frames compared."""
 import os, sys, time, torch
 os.environ.setdefault("LD_TUNING", "1")          # the library re-reads its knobs per call
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,15 +39,17 @@ if len(sys.argv) > 2 and sys.argv[2] == "ab":
     a, b = outs[True].int(), outs[False].int()
     diff = (a - b).abs()
     print(f"frames: {(diff > 0).float().mean().item():.4f} of the uint8 values differ, max {diff.max().item()} grey levels")
-elif len(sys.argv) > 2 and sys.argv[2] == "rcp":
+elif len(sys.argv) > 2 and sys.argv[2] in ("rcp", "m512"):
+    knob, names = {"rcp": ("LD_GN_FAST_RCP", ("sigmoid reciprocal v_rcp_f32    ", "sigmoid reciprocal IEEE division")),
+                   "m512": ("LD_GEMM_M512", ("Cin = Cout = 128 convs on 512 x 128 8-phase tiles ", "Cin = Cout = 128 convs on 128 x 128 two-stage tiles"))}[sys.argv[2]]
     outs = {}
     for rnd in range(3):
         for fast in ("1", "0"):
-            os.environ["LD_GN_FAST_RCP"] = fast
+            os.environ[knob] = fast
             vae.decode(lat)
             ms, o = timed()
             outs[fast] = o
-            print(f"round {rnd}: sigmoid reciprocal {'v_rcp_f32    ' if fast == '1' else 'IEEE division'}: {ms:.1f} ms per video")
+            print(f"round {rnd}: {names[0] if fast == '1' else names[1]}: {ms:.1f} ms per video")
     a, b = outs["1"].int(), outs["0"].int()
     diff = (a - b).abs()
     print(f"frames: {(diff > 0).float().mean().item():.4f} of the uint8 values differ, max {diff.max().item()} grey levels")
