@@ -80,8 +80,12 @@ class VAEDecoder:
         shape = (H + 2, W + 2, C)
         buf = self._win.get(name)
         if buf is None or tuple(buf.shape[1:]) != shape or buf.shape[0] < T + 2:
-            assert name not in self.cache, f"{name}: the chunk shape changed under a live cache"
-            buf = self._win[name] = torch.zeros(2 * T + 2, *shape, device=self.dev, dtype=BF)
+            old, buf = buf, torch.zeros(2 * T + 2, *shape, device=self.dev, dtype=BF)
+            if name in self.cache:                       # a longer chunk than any before, under a kept state: the halo moves along
+                assert old is not None and tuple(old.shape[1:]) == shape, f"{name}: the frame shape changed under a live cache"
+                buf[:2].copy_(old[self.cache[name]:self.cache[name] + 2])
+                self.cache[name] = 0
+            self._win[name] = buf
         pos = self.cache.get(name, 0)
         if pos + T + 2 > buf.shape[0]:
             src = buf[pos:pos + 2]

@@ -419,3 +419,60 @@ def test_verify_real_checkpoint_tool(tmp_path, capsys):
     assert mod.qkv_layout({name: torch.cat([v.reshape(d, d), q.reshape(d, d), k.reshape(d, d)])}, c, 0) is False
     assert mod.qkv_layout({name: torch.stack([q, k, v], 1).reshape(3 * d, d)}, c, 0) is False      # per-head interleaved
     capsys.readouterr()
+
+
+def test_vae_causal_conv_windows_keep_the_halo_in_place(monkeypatch):
+    """VAEDecoder's per-conv input windows (round 5): a chunk's producer writes behind the previous chunk's last two padded frames,
+    the conv's window starts two frames earlier, and the two frames move to the front only when the window would run past the end
+    of the conv's buffer -- the reference's per-conv cache (ContextParallelCausalConv3d.forward(x, clear_cache),
+    cp_enc_dec.py:436-466) without its copy out and copy in.  Host logic on CPU tensors, the conv launch stubbed: what the conv
+    would read is [the previous chunk's last two frames | this chunk's frames] (first chunk: its first frame three times), the
+    spatial border stays zero, the last chunk clears the state, a later decode starts fresh, a kept state continues."""
+    import torch
+    from landiff_amd import ops, vae as vae_mod
+    from landiff_amd.config import PipelineConfig
+    seen = []
+    monkeypatch.setattr(ops, "conv_cl", lambda xp, w, T, H, W, **kw: seen.append(xp.clone()) or None)
+    dec = vae_mod.VAEDecoder({}, PipelineConfig.tiny().vae, torch.device("cpu"))
+    dec.w = {"c.conv.weight": None, "c.conv.bias": None}
+    H, W, C = 3, 2, 8
+    frame = [0]
+
+    def chunk(T, clear):
+        win = dec._conv_window("c", T, H, W, C)
+        assert tuple(win.shape) == (T + 2, H + 2, W + 2, C) and win.is_contiguous()
+        ids = []
+        for t in range(T):
+            frame[0] += 1
+            win[2 + t, 1:-1, 1:-1] = float(frame[0])
+            ids.append(frame[0])
+        dec._causal_conv(win, "c", T, H, W, clear)
+        return ids
+
+    def check(xp, halo, ids):
+        want = list(halo) + list(ids)
+        assert [int(xp[t, 1, 1, 0]) for t in range(xp.shape[0])] == want, (want, [int(xp[t, 1, 1, 0]) for t in range(xp.shape[0])])
+        assert (xp[:, 1:-1, 1:-1].amin(dim=(1, 2, 3)) == xp[:, 1:-1, 1:-1].amax(dim=(1, 2, 3))).all()      # whole frames moved
+        assert float(xp[:, 0].abs().sum() + xp[:, -1].abs().sum() + xp[:, :, 0].abs().sum() + xp[:, :, -1].abs().sum()) == 0.0
+
+    for rep in range(2):                                    # two decodes on the same decoder: the second starts fresh
+        dec.cache = {}
+        seen.clear()
+        schedule = [9, 8, 8, 8, 8, 8]
+        prev = None
+        for i, T in enumerate(schedule):
+            ids = chunk(T, clear=(i == len(schedule) - 1))
+            check(seen[-1], [ids[0], ids[0]] if prev is None else prev[-2:], ids)
+            prev = ids
+            assert ("c" in dec.cache) == (i < len(schedule) - 1)
+        assert dec._win["c"].shape[0] == 2 * 9 + 2            # one buffer, two chunks + 2 frames long, reused throughout
+    # a kept state (streaming): decode(stream_keep) then continued chunks of other lengths, single frames included -- the halo is
+    # always the last two frames of the conv's padded input so far
+    dec.cache = {}
+    hist = chunk(5, clear=False)
+    for T in (2, 2, 1, 1, 3, 2, 1, 9, 1, 14, 2, 14):          # 14: longer than the buffer -- a new one, the halo moves along
+        halo = hist[-2:]
+        ids = chunk(T, clear=False)
+        check(seen[-1], halo, ids)
+        hist += ids
+    assert dec.cache
