@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
 // MEASURED (profiles/r05_vae_conv_route_ab.txt): alone in a loop 2.37 -> 2.16 ms per 8-frame launch (1135 vs 1031 TFLOP/s); inside
 // the VAE decode, same box, arms alternated: 337.4 / 336.7 ms per video against 337.4 / 335.7 -- no gain (in context the 128 x 128
 // tiles already run at ~1085) -- so it is a measured alternative of the VARIANTS build (LD_GEMM_M512=1 there), not a shipped route.
-// Its reason to stay under test: the DiT GEMMs' half-empty last tile column.
+// (For the DiT GEMMs' half-empty last tile column it would not pay at the headline shape: DESIGN.md section 9.)
 // ------------------------------------------------------------------------------------------------
 template <bool CONV, int EPI>
 __global__ __launch_bounds__(512, 2) void ld_gemm8p_m512_kernel(GemmParams p) {
