@@ -411,7 +411,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&a
 //           of V^T [B][heads][64][Npad] rows, 8 tokens each (batch boundary and M are multiples of 8 rows).
 // Rows [Ntok, Npad) of Q / K / V^T are never written: the caller zero-fills those workspaces once.
 // LDS: QKV_REGION bytes per wave (wave-private: only the in-order execution of a wave's own DS instructions orders it).
-constexpr int QKV_REGION = 17408;      // >= 32 * CW_STRIDE * 4 (q/k staging) and 64 * (128 * 2 + 16) (v tile at 128 rows per wave)
+constexpr int QKV_REGION = 9216;       // >= 32 * CW_STRIDE * 4 (q/k staging) and 64 * (64 * 2 + 16) (v tile: 64 rows of a wave tile at a time)
 template <int MI, typename Hook = NoHook>
 __device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&acc)[2 * MI][4], char* smem, int wave, int lane,
                                                int row0, int col0w, Hook&& hook = Hook{}) {
@@ -488,32 +488,41 @@ __device__ __forceinline__ void qkv_epilogue16(const GemmParams& p, f32x4_t (&ac
     if constexpr (MI > 2) row_block(std::integral_constant<int, 2>{});
     if constexpr (MI > 3) row_block(std::integral_constant<int, 3>{});
   } else {
-    constexpr int ROWB = MI * 64 + 16;           // bytes per d row of the transposed tile (MI * 32 rows + pad, 16-byte aligned)
-    static_assert(64 * ROWB <= QKV_REGION, "v tile does not fit its LDS region");
+    // (round 6) a 128-row wave tile goes through the transposed tile in two 64-row halves: 9 KB instead of 17 KB per wave, so that
+    // the whole epilogue staging (8 x QKV_REGION) stays clear of K-tile buffer 0 and the persistent kernel can request the next
+    // tile's first K-tile from inside this epilogue too (PREFETCH in ld_gemm8p_kernel).  Wave-private LDS: the second half's
+    // stores follow the first half's loads in the wave's own DS queue, which executes in order.
+    constexpr int VH = MI >= 4 ? 2 : 1;          // halves
+    constexpr int MH = MI / VH;                  // 32-row blocks per half
+    constexpr int ROWB = MH * 64 + 16;           // bytes per d row of the transposed tile (MH * 32 rows + pad, 16-byte aligned)
+    static_assert(MI % VH == 0 && 64 * ROWB <= QKV_REGION, "v tile does not fit its LDS region");
     float bj[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bj[j] = bf2f(p.bias[col0w + j * 16 + (lane & 15)]);
     hook();
 #pragma unroll
-    for (int i = 0; i < 2 * MI; ++i)
+    for (int vh = 0; vh < VH; ++vh) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        u32x2_t w2;
-        w2[0] = pack_bf16x2(acc[i][j][0] + bj[j], acc[i][j][1] + bj[j]);
-        w2[1] = pack_bf16x2(acc[i][j][2] + bj[j], acc[i][j][3] + bj[j]);
-        *(u32x2_t*)(reg + (j * 16 + (lane & 15)) * ROWB + (i * 16 + (lane >> 4) * 4) * 2) = w2;
-      }
-    constexpr int CPR = MI * 4;                  // 16-byte chunks (8 rows) per d row
+      for (int i = 0; i < 2 * MH; ++i)
 #pragma unroll
-    for (int it = 0; it < CPR; ++it) {           // 64 * CPR chunks, 64 per trip
-      const int id = it * 64 + lane;
-      const int d = id / CPR, c = id - d * CPR;
-      const int gm = row0 + c * 8;
-      const u32x4_t val = *(const u32x4_t*)(reg + d * ROWB + c * 16);
-      if (gm < p.M) {
-        const int b = gm >= bnd ? b0 + 1 : b0;
-        const int n = gm - b * p.Ntok;
-        __builtin_nontemporal_store(val, (u32x4_t*)(p.vt_out + (((long)b * p.heads + h) * 64 + d) * p.Npad + n));
+        for (int j = 0; j < 4; ++j) {
+          u32x2_t w2;
+          w2[0] = pack_bf16x2(acc[vh * 2 * MH + i][j][0] + bj[j], acc[vh * 2 * MH + i][j][1] + bj[j]);
+          w2[1] = pack_bf16x2(acc[vh * 2 * MH + i][j][2] + bj[j], acc[vh * 2 * MH + i][j][3] + bj[j]);
+          *(u32x2_t*)(reg + (j * 16 + (lane & 15)) * ROWB + (i * 16 + (lane >> 4) * 4) * 2) = w2;
+        }
+      constexpr int CPR = MH * 4;                // 16-byte chunks (8 rows) per d row
+#pragma unroll
+      for (int it = 0; it < CPR; ++it) {         // 64 * CPR chunks, 64 per trip
+        const int id = it * 64 + lane;
+        const int d = id / CPR, c = id - d * CPR;
+        const int gm = row0 + vh * MH * 32 + c * 8;
+        const u32x4_t val = *(const u32x4_t*)(reg + d * ROWB + c * 16);
+        if (gm < p.M) {
+          const int b = gm >= bnd ? b0 + 1 : b0;
+          const int n = gm - b * p.Ntok;
+          __builtin_nontemporal_store(val, (u32x4_t*)(p.vt_out + (((long)b * p.heads + h) * 64 + d) * p.Npad + n));
+        }
       }
     }
   }
@@ -767,11 +776,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 4 : 2) void ld_gemm
 
 // Two 1 KB LDS-DMA pieces of a half-tile through a raw buffer descriptor (rebuilt from its scalars at every use: loop-invariant
 // SGPR values for the compiler): per-lane byte offsets o0 / o1, wave-uniform K offset `ko` in an SGPR -- no vector ALU per piece.
+#ifndef LD_GEMM_ABL   // timing-only builds (WRONG results): bit 0 = no LDS-DMA in the main loop, bit 1 = fragments read once per tile,
+#define LD_GEMM_ABL 0 // bit 2 = every K-tile re-reads K-tiles 0 / 1 (L2 hits), bit 3 = no vmcnt waits, bit 4 = every second LDS-DMA piece only
+#endif
 template <int OFF>
 __device__ __forceinline__ void stage_pieces(const bf16_t* base, int bytes, char* lds, uint32_t o0, uint32_t o1, int ko) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + OFF), 16, o0, ko, 0, 0);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + OFF + 1024), 16, o1, ko, 0, 0);
+  if (!(LD_GEMM_ABL & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + OFF + 1024), 16, o1, ko, 0, 0);
 }
 
 template <int OFF>
@@ -810,10 +822,11 @@ __device__ __forceinline__ void stage_piece1(const bf16_t* base, int bytes, char
 //     XCD-grouped raster.  The epilogue's LDS staging lives at the END of the 160 KB, clear of K-tile buffer 0, so the first
 //     K-tile of the NEXT tile is requested before the epilogue starts (right after the epilogue's own first loads have been
 //     issued: loads and LDS-DMA retire in order) and lands under it: a tile no longer pays workgroup launch, argument loads and
-//     the first DMA round trip.  (The fused-qkv epilogue needs 136 KB of staging and keeps its prologue after the epilogue.)
+//     the first DMA round trip.  (Round 6: the fused-qkv epilogue too -- its V^T tile goes through LDS in two halves, 72 KB of staging.)
 // Measured (tools/gemm_ab.py, profiles/r03_gemm_*): bit-identical outputs; see DESIGN.md section 4.
 // ------------------------------------------------------------------------------------------------
 constexpr int LD_LDS_TOTAL = 160 * 1024;
+
 #ifdef LD_GEMM_TRACE   // timing builds (tools/gemm_tile_trace.py): per tile of ld_gemm8p_kernel start / end of main loop / end, XCC_ID, HW_ID
 __device__ unsigned long long* g_gemm_trace = nullptr;     // [0]: record counter, then 4 words per record
 __device__ int g_gemm_trace_cap = 0;
@@ -825,7 +838,13 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
   constexpr int SLOT = 128 * 128, KBUF = 4 * SLOT;        // 16 KB half-tile slot (128 rows x 128 B); A0 A1 B0 B1 per K-tile
   constexpr int EPI_BYTES = (EPI == EPI_QKV) ? 8 * QKV_REGION : 8 * 32 * CW_STRIDE * 4;
   constexpr int EPI_OFF = (LD_LDS_TOTAL - EPI_BYTES) & ~15;      // epilogue staging at the end of the LDS
-  constexpr bool PREFETCH = EPI_OFF >= KBUF;              // K-tile buffer 0 is free while the epilogue runs
+  // K-tile buffer 0 is free while the epilogue runs.  Not for the fused-qkv epilogue, although its staging has left buffer 0 alone
+  // since round 6: measured 0.745 ms with, 0.734 ms without the early request (profiles/r06_gemm_two_phase_ab.txt; -DLD_QKV_PREFETCH: A/B build)
+#ifdef LD_QKV_PREFETCH
+  constexpr bool PREFETCH = EPI_OFF >= KBUF;
+#else
+  constexpr bool PREFETCH = EPI_OFF >= KBUF && EPI != EPI_QKV;
+#endif
   constexpr bool SWAPACC = EPI != EPI_QKV;                // C^T accumulator blocks: 16-byte epilogue staging stores (gemm_epilogue16<SWAP>)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -891,6 +910,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
   const int nk = p.K / BK;
   const int cpt = CONV ? p.Cin / BK : 1;
   auto koff_a = [&](int kt) -> int {                      // byte offset of K-tile kt within an A row
+    if (LD_GEMM_ABL & 4) kt &= 1;                         // (timing build: every K-tile re-reads K-tiles 0 / 1 -- L2 hits only)
     if (CONV) {
       const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
       const int khw = p.kH * p.kW;
@@ -908,7 +928,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
   };
   auto stage_w = [&](const Src& s, auto bufc, auto gc, int kt) {
     constexpr int OFF = decltype(bufc)::value * KBUF + (2 + decltype(gc)::value) * SLOT;
-    stage_pieces<OFF>(s.w, s.w_bytes, my_piece, offW[decltype(gc)::value][0], offW[decltype(gc)::value][1], kt * (BK * 2));
+    stage_pieces<OFF>(s.w, s.w_bytes, my_piece, offW[decltype(gc)::value][0], offW[decltype(gc)::value][1], ((LD_GEMM_ABL & 4) ? (kt & 1) : kt) * (BK * 2));
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -969,6 +989,71 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+#ifndef LD_GEMM_PH4   // round 6: TWO phases of 32 MFMAs per K-tile (-DLD_GEMM_PH4: the four phases of 16 of rounds 3-5, for A/B builds)
+  // Half the barriers and half the role switches between the two waves of a SIMD per K-tile; the same MFMAs on the same accumulators
+  // in the same order -> the same bits.  Measured -2.6 % on the four DiT GEMMs (profiles/r06_gemm_two_phase_ab.txt).
+  auto mma2 = [&](auto hc, auto g0c, bf16x8_t (&bA)[2][2], auto g1c, bf16x8_t (&bB)[2][2]) {
+    constexpr int H = decltype(hc)::value, G0 = decltype(g0c)::value, G1 = decltype(g1c)::value;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_live) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[H * 4 + i][G0 * 2 + j] = SWAPACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bA[j][ks], a[i][ks], acc[H * 4 + i][G0 * 2 + j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bA[j][ks], acc[H * 4 + i][G0 * 2 + j], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[H * 4 + i][G1 * 2 + j] = SWAPACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bB[j][ks], a[i][ks], acc[H * 4 + i][G1 * 2 + j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bB[j][ks], acc[H * 4 + i][G1 * 2 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // P0: read B_g0, B_g1, A_h0 (16 fragments); stage B_1 / A_1 of K-tile kt + 1; MFMA (h0, g0), (h0, g1)
+  // P1: read A_h1 (8);                        stage A_0 / B_0 of K-tile kt + 2; MFMA (h1, g1), (h1, g0)
+  // A slot is re-staged as early as ONE phase after its last read, so every wave retires its fragment reads (lgkmcnt 0) BEFORE
+  // the first barrier of the reading phase: a wave that has passed the barrier ending that phase knows that every wave of both
+  // rows holds its fragments in registers.
+  auto ktile = [&](auto bufc, int kt) {
+    constexpr int B = decltype(bufc)::value;
+    using Bc = std::integral_constant<int, B>;
+    using Nc = std::integral_constant<int, B ^ 1>;
+    // P0.  LDS-DMA in flight on entry (oldest first): A_1(kt) [2], A_0 / B_0(kt + 1) [4]
+    if (!(LD_GEMM_ABL & 2) || kt == 0) {
+      read_b(Bc{}, I0{}, b0);
+      read_b(Bc{}, I1{}, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(Bc{}, I0{});
+    }
+    if (kt + 1 < nk) {
+      if (!(LD_GEMM_ABL & 1)) { stage_w(src, Nc{}, I1{}, kt + 1); stage_a(src, Nc{}, I1{}, kt + 1); }
+      if (LD_GEMM_ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // A_1(kt) has landed: read in P1, one barrier later
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    bar(); mma2(I0{}, I0{}, b0, I1{}, b1); bar();
+    // P1.  In flight: A_0 / B_0(kt + 1) [4], B_1 / A_1(kt + 1) [4]
+    if (!(LD_GEMM_ABL & 2)) read_a(Bc{}, I1{});
+    if (kt + 2 < nk) {
+      if (!(LD_GEMM_ABL & 1)) { stage_a(src, Bc{}, I0{}, kt + 2); stage_w(src, Bc{}, I0{}, kt + 2); }
+      if (LD_GEMM_ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // A_0 / B_0 / B_1 of K-tile kt + 1 have landed
+    } else if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // nothing new was issued: only A_1(kt + 1) may stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    bar(); mma2(I1{}, I1{}, b1, I0{}, b0); bar();
+  };
+#else
   auto ktile = [&](auto bufc, int kt) {
     constexpr int B = decltype(bufc)::value;
     using Bc = std::integral_constant<int, B>;
@@ -996,6 +1081,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_kernel(GemmParams p) {
     }
     bar(); mma(I1{}, I0{}, b0); bar();
   };
+#endif
 
   set_offsets(0, true);
   bool k0_staged = false;                                 // K-tile 0 of the tile about to start is already on its way
@@ -1480,6 +1566,62 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_n128_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+#ifndef LD_GEMM_PH4   // two phases of 16 MFMAs per K-tile (ld_gemm8p_kernel's round-6 loop on the half tile)
+  auto mma2 = [&](auto hc, auto g0c, bf16x8_t (&bA)[2][2], auto g1c, bf16x8_t (&bB)[2][2]) {
+    constexpr int H = decltype(hc)::value, G0 = decltype(g0c)::value, G1 = decltype(g1c)::value;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_live) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[H * 2 + i][G0 * 2 + j] = SWAPACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bA[j][ks], a[i][ks], acc[H * 2 + i][G0 * 2 + j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bA[j][ks], acc[H * 2 + i][G0 * 2 + j], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[H * 2 + i][G1 * 2 + j] = SWAPACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bB[j][ks], a[i][ks], acc[H * 2 + i][G1 * 2 + j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bB[j][ks], acc[H * 2 + i][G1 * 2 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto ktile = [&](auto bufc, int kt) {      // (LDS-DMA instructions per wave: an A half = 2, a W half = 1)
+    constexpr int B = decltype(bufc)::value;
+    using Bc = std::integral_constant<int, B>;
+    using Nc = std::integral_constant<int, B ^ 1>;
+    // P0.  In flight on entry (oldest first): A_1(kt) [2], A_0 / W_0(kt + 1) [3]
+    read_b(Bc{}, I0{}, b0);
+    read_b(Bc{}, I1{}, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(Bc{}, I0{});
+    if (kt + 1 < nk) {
+      stage_w(src, Nc{}, I1{}, kt + 1); stage_a(src, Nc{}, I1{}, kt + 1);
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // A_1(kt) has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    bar(); mma2(I0{}, I0{}, b0, I1{}, b1); bar();
+    // P1.  In flight: A_0 / W_0(kt + 1) [3], W_1 / A_1(kt + 1) [3]
+    read_a(Bc{}, I1{});
+    if (kt + 2 < nk) {
+      stage_a(src, Bc{}, I0{}, kt + 2); stage_w(src, Bc{}, I0{}, kt + 2);
+      asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   // A_0 / W_0 / W_1 of K-tile kt + 1 have landed
+    } else if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    bar(); mma2(I1{}, I1{}, b1, I0{}, b0); bar();
+  };
+#else
   auto ktile = [&](auto bufc, int kt) {
     constexpr int B = decltype(bufc)::value;
     using Bc = std::integral_constant<int, B>;
@@ -1507,6 +1649,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_n128_kernel(GemmParams p) {
     }
     bar(); mma(I1{}, I0{}, b0); bar();
   };
+#endif
 
   bool k0_staged = false;
   for (int u = blockIdx.x; u < nhalf; u += gridDim.x) {

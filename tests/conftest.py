@@ -1,5 +1,7 @@
 import os
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -8,6 +10,8 @@ os.environ.setdefault("LANDIFF_SKIP_INIT", "1")      # importing `landiff` would
 os.environ.setdefault("LD_TUNING", "1")              # the library re-reads its LD_* knobs on every call (tests alternate kernel forms in one process)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):
@@ -25,3 +29,79 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible (these tests must not silently skip)")
     return torch.device("cuda:0")
+
+
+class OracleJobs:
+    """The slow oracle legs of the full-size GPU tests (tests/oracle_jobs.py) as child processes on the host cores: started right
+    after collection for the selected tests, joined by the tests themselves -- the GPU box has 256 hardware threads that the GPU
+    tests in between leave idle, and the oracle never touches the GPU.  A job nobody started yet is started by the first result()
+    call (a single test run on its own)."""
+
+    def __init__(self):
+        self.dir = tempfile.mkdtemp(prefix="ld_oracle_jobs_")
+        self.procs = {}
+
+    def start(self, name):
+        if name in self.procs:
+            return
+        out = os.path.join(self.dir, name + ".pt")
+        log = open(os.path.join(self.dir, name + ".log"), "w")
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")     # CPU only: the checker never sees the GPU
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "oracle_jobs.py"), name, out], cwd=ROOT, env=env,
+                             stdout=log, stderr=subprocess.STDOUT)
+        self.procs[name] = (p, out, log)
+
+    def result(self, name, timeout=1700.0):
+        import torch
+        self.start(name)
+        p, out, log = self.procs[name]
+        rc = p.wait(timeout=timeout)
+        log.close()
+        if rc != 0 or not os.path.exists(out):
+            with open(os.path.join(self.dir, name + ".log")) as f:
+                pytest.fail(f"oracle job {name} failed (exit code {rc}):\n{f.read()[-4000:]}")
+        d = torch.load(out, weights_only=False)
+        return d["result"], d["seconds"]
+
+    def close(self):
+        for p, _, log in self.procs.values():
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+            if not log.closed:
+                log.close()
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
+_JOBS = None
+
+
+def pytest_collection_finish(session):
+    """Start the oracle children of the selected tests now, so that they run under the GPU tests that come first."""
+    global _JOBS
+    from oracle_jobs import CONSUMERS
+    want = []
+    for item in session.items:
+        for test, jobs in CONSUMERS.items():
+            if item.nodeid.endswith("::" + test):
+                want += jobs
+    if want and not session.config.option.collectonly:
+        _JOBS = OracleJobs()
+        for name in want:
+            _JOBS.start(name)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    global _JOBS
+    if _JOBS is not None:
+        _JOBS.close()
+        _JOBS = None
+
+
+@pytest.fixture(scope="session")
+def oracle_bg():
+    global _JOBS
+    if _JOBS is None:
+        _JOBS = OracleJobs()
+    return _JOBS

@@ -152,25 +152,17 @@ def test_dit_layer_full_shape_vs_oracle(cuda):
     assert err.mean().item() / ref.abs().mean().item() < 1e-2, (err.mean().item(), ref.abs().mean().item())
 
 
-def test_dit_multi_layer_step_full_shape_vs_oracle(cuda):
+def test_dit_multi_layer_step_full_shape_vs_oracle(cuda, oracle_bg):
     """A whole denoiser evaluation at the BASELINE shape with the depth cut to 3 control + 3 main layers (B=2 CFG pair, 13 x 30 x 45
     image tokens + 226 text tokens, hidden 1920): patch / text embedding with the semantic condition added on the control side,
     the control chain with its zero-linears, three resident control states added into the main chain, sat's final_layernorm,
     the final adaLN layer, unpatchify, denoiser scaling and the CFG combine -- ControlDiTRunner.step against the fp32 oracle
-    on the host cores (~1 min).  What only appears at this size: the fused qkv launch, persistent 8-phase GEMMs with M-split
+    on the host cores (~1 min, in a child process since the start of the session: tests/oracle_jobs.py: job_dit_3p3_eps).  What only appears at this size: the fused qkv launch, persistent 8-phase GEMMs with M-split
     tails, the 64-row attention tile, workspaces shared across layers while several control states are live."""
-    import dataclasses
-    from landiff_amd.config import PipelineConfig
     from landiff_amd.dit import ControlDiTRunner
-    from landiff_amd.weights import dit_spec, init_state
-    from oracle.dit import ControlDiTOracle
-    d3 = dataclasses.replace(PipelineConfig.full().dit, layers_main=3, layers_control=3)
-    sd_main, sd_ctrl = init_state(dit_spec(d3, False), 1), init_state(dit_spec(d3, True), 2)
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn(1, d3.latent_frames, d3.in_channels, d3.latent_h, d3.latent_w, generator=g)
-    ctx = torch.randn(1, d3.text_len, d3.text_dim, generator=g).to(torch.bfloat16).float()
-    sem = (0.5 * torch.randn(d3.latent_frames, d3.in_channels, d3.latent_h, d3.latent_w, generator=g)).to(torch.bfloat16)
-    timestep, c_out, c_skip, scale = 500, -0.8, 0.6, 4.0
+    from oracle_jobs import dit_3p3_inputs
+    d3, sd_main, sd_ctrl, x, ctx, sem, timestep = dit_3p3_inputs()
+    c_out, c_skip, scale = -0.8, 0.6, 4.0
     run = ControlDiTRunner(sd_main, sd_ctrl, d3, cuda)
     assert run.fuse_qkv
     run.set_condition(ctx, sem)
@@ -182,10 +174,7 @@ def test_dit_multi_layer_step_full_shape_vs_oracle(cuda):
     out2 = torch.empty(1, *x.shape[1:], device=cuda)
     run.step(x.to(cuda), timestep, c_out, c_skip, scale, out2)
     assert torch.equal(out2.cpu(), outs[scale])                       # run-to-run deterministic
-    torch.set_num_threads(min(64, max(torch.get_num_threads(), torch.get_num_threads() * 8)))
-    with torch.no_grad():
-        eps = ControlDiTOracle(sd_main, sd_ctrl, d3, torch.float32)(
-            torch.cat([x, x]), torch.full((2,), float(timestep)), torch.cat([torch.zeros_like(ctx), ctx]), sem.float()).float()
+    eps, _ = oracle_bg.result("dit_3p3_eps")
     den = eps * c_out + torch.cat([x, x]) * c_skip                   # Denoiser.forward: [uncond, cond]
     ref = {0.0: den[:1], 1.0: den[1:], scale: den[:1] + scale * (den[1:] - den[:1])}
     for s_cfg, amp in ((0.0, 1.0), (1.0, 1.0), (scale, 2 * scale - 1)):
@@ -394,26 +383,21 @@ def test_vae_level0_resblock_full_resolution_vs_oracle(cuda):
     assert mean_err < max(2 * mean_floor, 5e-3), (mean_err, mean_floor)
 
 
-def test_vae_full_resolution_two_chunks_vs_oracle(cuda):
+def test_vae_full_resolution_two_chunks_vs_oracle(cuda, oracle_bg):
     """The whole 3D-VAE decoder at 480 x 720 on the reference's chunk schedule: 5 latent frames = chunk 0:3 (odd T: replicated
     first-frame halo, the first-frame rule of both time upsamples and of the SpatialNorm zq gather, 9 frames) + chunk 3:5
     continued from the kept causal-conv caches (8 frames) -- conv_in, mid blocks, all four levels, conv_out, post-process, uint8 --
-    against the fp32 oracle on the host cores (~110 TFLOP of fp32 conv3d: the slowest test of the suite, a few minutes).
+    against the fp32 oracle (~110 TFLOP of fp32 conv3d, a few minutes of the host cores: it runs in a child process from the
+    start of the session, tests/oracle_jobs.py: job_vae_two_chunks, and is joined here).
     No bf16-oracle floor at this size (a bf16 conv3d on the host is several times slower still); measured on MI355X: first chunk
     max 0.058 / mean 0.0035 of the [0, 1] video range, continued chunk 0.044 / 0.0035, uint8 frames 0.9 grey levels apart on
     average -- the level of the tiny-size test against the bf16 oracle (tests/test_gpu_stages.py::test_vae_decode: 6e-2 / 4e-3).
     The bounds below leave ~1.4x of that for a different summation order of the GroupNorm statistics.
     Reference: landiff/diffusion/vae_modules/cp_enc_dec.py:416-473,605-633,1034-1069, landiff/diffusion/dif_infer.py:245-271."""
-    import time
-    from landiff_amd.config import VAEConfig
     from landiff_amd.vae import VAEDecoder
-    from landiff_amd.weights import init_state, vae_spec
-    from oracle.vae import VAEDecoderOracle, post_process, to_uint8_frames
-    cfg = VAEConfig()
-    sd = init_state(vae_spec(cfg), 41)
-    g = torch.Generator().manual_seed(8)
-    Tl, h, w = 5, 60, 90
-    latent = torch.randn(1, Tl, cfg.z_channels, h, w, generator=g).to(torch.bfloat16).float()
+    from oracle.vae import to_uint8_frames
+    from oracle_jobs import vae_two_chunks_inputs
+    cfg, sd, latent = vae_two_chunks_inputs()
     vae = VAEDecoder(sd, cfg, cuda)
     frames, video = vae.decode(latent.to(cuda), want_float=True)
     assert tuple(frames.shape) == (17, 480, 720, 3) and frames.dtype == torch.uint8
@@ -425,16 +409,12 @@ def test_vae_full_resolution_two_chunks_vs_oracle(cuda):
     del vae, fa, fb
     torch.cuda.empty_cache()
     assert torch.equal(frames, to_uint8_frames(video))                      # uint8 = trunc(255 x float video), exactly
-    torch.set_num_threads(min(64, max(torch.get_num_threads(), torch.get_num_threads() * 8)))
-    t0 = time.perf_counter()
-    orc = VAEDecoderOracle(sd, cfg, torch.float32)
-    ref = post_process(orc.decode_latent(latent.permute(0, 2, 1, 3, 4)))[0]  # [3, 17, 480, 720]
-    dt = time.perf_counter() - t0
+    ref, dt = oracle_bg.result("vae_two_chunks")                            # [3, 17, 480, 720]
     assert ref.shape == video.shape == (3, 17, 480, 720)
     err = (video - ref).abs()
     per_chunk = [(err[:, :9].max().item(), err[:, :9].mean().item()), (err[:, 9:].max().item(), err[:, 9:].mean().item())]
     grey = (frames.float() - to_uint8_frames(ref).float()).abs()
-    print(f"VAE 480x720, 5 latent frames -> 17 frames vs fp32 oracle ({dt:.0f} s of host CPU): first chunk max {per_chunk[0][0]:.4f} "
+    print(f"VAE 480x720, 5 latent frames -> 17 frames vs fp32 oracle ({dt:.0f} s of host CPU, in the background): first chunk max {per_chunk[0][0]:.4f} "
           f"mean {per_chunk[0][1]:.5f}, continued chunk max {per_chunk[1][0]:.4f} mean {per_chunk[1][1]:.5f}; uint8 frames differ by "
           f"{grey.mean().item():.3f} grey levels on average, {int(grey.max().item())} at most; oracle video std {ref.std().item():.3f}")
     for mx, mean in per_chunk:

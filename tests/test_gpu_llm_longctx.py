@@ -89,55 +89,22 @@ def test_kv_attn_split_vs_torch_over_context_lengths(cuda, nsplit):
     print(f"ld_llm_kv_attn nsplit={nsplit}: worst error vs the same-dtype-flow restatement {worst:.5f} of the output range")
 
 
-def test_llm_two_blocks_full_width_decode_at_real_context_lengths_vs_oracle(cuda):
+def test_llm_two_blocks_full_width_decode_at_real_context_lengths_vs_oracle(cuda, oracle_bg):
     """The AR decoder at its real width (2048, 16 heads x 128, MLP 11008, vocabulary 2055, CFG pair) cut to 2 blocks so that the
     fp32 oracle runs 1 243 cached decode steps in about a minute: CFG logits of the HIP decode chain (teacher-forced) against
-    the oracle at the KV lengths where split boundaries, the 256-key limit per split and the longest context lie."""
-    from landiff_amd.config import LLMConfig
+    the oracle at the KV lengths where split boundaries, the 256-key limit per split and the longest context lie.  The fp32 and
+    the bf16 oracle decode run in child processes from the start of the session (tests/oracle_jobs.py: job_llm_two_blocks_*)."""
     from landiff_amd.llm import LLMRunner
-    from landiff_amd.weights import init_state, llm_spec
-    from oracle.llm import LLMOracle, forced_schedule, rope_table
-    cfg = dataclasses.replace(LLMConfig(), num_layers=2)
-    sd_dev = init_state(llm_spec(cfg), 5, dtype=torch.bfloat16, device=cuda)
-    sd = {k: v.cpu() for k, v in sd_dev.items()}
-    run = LLMRunner(sd_dev, cfg, cuda)
-    del sd_dev
-    g = torch.Generator().manual_seed(6)
-    text = torch.randn(64, cfg.text_dim, generator=g).to(torch.bfloat16)
-    fed = torch.randint(0, cfg.visual_vocab, (2000,), generator=g)
+    from oracle_jobs import llm_two_blocks_inputs
+    cfg, sd, text, fed, S, full_len, steps, check_it = llm_two_blocks_inputs()
+    run = LLMRunner({k: v.to(cuda) for k, v in sd.items()}, cfg, cuda)
     log = []
     run.sample(text.to(cuda), guidance_scale=7.5, motion_score=0.1, seed=42, logits_log=log, teacher_fed=fed.to(cuda))
     dev = torch.cat(log, 0).cpu()                                      # [1 + steps, vocab]: prefill, then one row per decode step
-    S = 64 + 4 - 1                                                     # prefix = [BOS][frames][motion][text x 64][START_I]
-    full_len = forced_schedule(cfg, S, 13)[0]
-    steps = full_len - (S + 1) - 1
     assert dev.shape[0] == steps + 1 and steps >= 1240, (dev.shape, steps)
-    # decode step `it` appends position S + 1 + it: KV length S + 2 + it
-    want_len = [128, 255, 256, 257, 700, 1024, 1300, S + 1 + steps]
-    check_it = sorted({L - S - 2 for L in want_len})
     assert check_it[0] >= 0 and check_it[-1] == steps - 1
-    torch.set_num_threads(min(64, max(torch.get_num_threads(), torch.get_num_threads() * 8)))
-
-    def oracle_logits(dtype):
-        sdt = {k: (v.to(dtype) if v.dtype == torch.bfloat16 else v) for k, v in sd.items()}     # no per-call weight casts
-        orc = LLMOracle(sdt, cfg, dtype)
-        with torch.no_grad():
-            feats = orc.prefix_features(text.float(), 13.0, 0.1, True)
-            assert feats.shape[1] - 1 == S
-            cos, sin = rope_table(cfg.head_dim, full_len + 1, cfg.rope_theta)
-            cache = [None] * cfg.num_layers
-            emb = sd["visual_embedding_model.tok_emb_code.weight"]
-            out = {}
-            orc.gpt_step(feats, cache, cos[None, : S + 1], sin[None, : S + 1])
-            for it in range(steps):
-                f = emb[fed[it]].float().reshape(1, 1, -1)
-                pos = S + 1 + it
-                lg = orc.gpt_step(torch.cat([f, f], 0), cache, cos[None, pos:pos + 1], sin[None, pos:pos + 1]).float()
-                if it in check_it:
-                    out[it] = lg[1:] + 7.5 * (lg[:1] - lg[1:])
-        return out
-
-    ref32, ref16 = oracle_logits(torch.float32), oracle_logits(torch.bfloat16)
+    ref32, _ = oracle_bg.result("llm_two_blocks_fp32")
+    ref16, _ = oracle_bg.result("llm_two_blocks_bf16")
     rel = lambda a, b: ((a.float() - b.float()).abs().max() / b.float().abs().max()).item()
     rows = []
     for it in check_it:
