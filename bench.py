@@ -317,7 +317,14 @@ def main():
                     help="BASELINE configs[4] only (with --stream-chunks): e4m3 operands for the DiT's qkv / dense / 4h / 4h->h "
                          "linears -- mx (default): MXFP8 block scales, quantisation fused into LayerNorm / GELU epilogue; row: "
                          "per-row scales with quantise passes.  Reduced precision: not the headline metric, own workload name and dtype")
+    ap.add_argument("--with-t5", action="store_true",
+                    help="SECONDARY line (SURVEY 8d: 'end-to-end incl. both T5 encoders'): every step also runs the two text encoders "
+                         "on the MI355X kernels -- FLAN-T5-XXL over 64 prompt tokens (LLM condition) and T5-v1.1-XXL over 226 padded "
+                         "tokens (DiT context), random-init weights at true shapes -- and feeds their states to the pipeline; the "
+                         "stage appears as `t5` in stage_seconds_rank0.  Not the BASELINE metric (which starts at the encoder outputs)")
     args = ap.parse_args()
+    if args.with_t5 and (args.tiny or args.stream_chunks or args.prompts_per_step > 1):
+        raise SystemExit("--with-t5 applies to the headline workload only")
     if args.prompts_per_step > 1 and (args.stream_chunks or args.fp8_gemm or args.tiny):
         raise SystemExit("--prompts-per-step applies to the headline workload only")
     if args.fp8_gemm and not args.stream_chunks:
@@ -367,7 +374,22 @@ def main():
     import dataclasses
     inps = [dataclasses.replace(inp, seed=inp.seed + 1000 * i) for i in range(P)]
 
+    t5 = None
+    if args.with_t5:
+        from landiff_amd.t5 import T5Config, T5EncoderRunner, random_state
+        tcfg = T5Config()
+        t5 = {"flan": T5EncoderRunner(random_state(tcfg, 77, dev), tcfg, dev), "v11": T5EncoderRunner(random_state(tcfg, 78, dev), tcfg, dev)}
+        gi = torch.Generator().manual_seed(4242 + rank)
+        ids_llm = torch.randint(0, tcfg.vocab, (64,), generator=gi).to(dev)
+        ids_dit = torch.randint(0, tcfg.vocab, (cfg.dit.text_len,), generator=gi).to(dev)      # 226, padded, unmasked (FrozenT5Embedder)
+
     def one_step():
+        nonlocal inp
+        if t5 is not None:
+            t_0 = time.perf_counter()
+            inp = dataclasses.replace(inp, llm_text_emb=t5["flan"].encode(ids_llm).float(), dit_context=t5["v11"].encode(ids_dit)[None].float())
+            torch.cuda.synchronize()
+            pipe.timings["t5"] = pipe.timings.get("t5", 0.0) + time.perf_counter() - t_0
         if P > 1:
             frames = torch.cat(pipe.generate_many(inps), dim=0)          # [P * 49, H, W, 3]
         else:
@@ -378,7 +400,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     sampler = ClockPowerSampler(dev)
-    calib = calibrate(dev, sampler) if rank == 0 else None
+    calib = calibrate(dev, sampler)           # EVERY rank: the pool's GPUs differ by +-5 % under the power cap (per_rank.calibration)
     pipe.timings = {}
     pipe.dit.attn_events = []                 # HIP events around every attention launch: the roofline object's `achieved`
     pipe.dit.gemm_events = None               # (the GEMM events are collected in a separate, untimed step below)
@@ -415,7 +437,12 @@ def main():
         pipe.timings, pipe.dit.attn_events, pipe.dit.overlap = keep_t, keep_a, keep_o
     reports = gather_rank_reports({"rank": rank, "frames_per_s": round(n_frames * args.steps / local_elapsed, 4),
                                    "stage_seconds": {k: round(v, 3) for k, v in stage_s.items()},
-                                   "cores": len(my_cores) if my_cores else None}, world if use_dist else 1)
+                                   "cores": len(my_cores) if my_cores else None,
+                                   "calibration": {"mfma_tflops": calib["mfma_tflops"], "hbm_gbs": calib["hbm_gbs"],
+                                                   "mfma_loop_sclk_mhz": calib["mfma_loop_sclk_mhz"],
+                                                   "timed_region_sclk_mhz": clocks["mean_sclk_mhz"] if clocks else None,
+                                                   "timed_region_power_w": clocks["mean_power_w"] if clocks else None}},
+                                  world if use_dist else 1)
     if rank == 0:
         d = cfg.dit
         ev_all = pipe.dit.attn_events
@@ -482,7 +509,7 @@ def main():
                                     "what": "315 TFLOP of causal 3D / 2D convolutions per 49-frame video / the vae stage's wall time (norm, upsample and uint8 passes included)"}
         serving = P > 1
         res = {
-            "metric": METRIC if not serving else METRIC + " [SERVING MODE: %d prompts per GPU and step, AR decode overlapped -- not the BASELINE configuration]" % P,
+            "metric": (METRIC + " [SECONDARY: incl. both T5-XXL text encoders on the GPU, SURVEY 8d]") if args.with_t5 else METRIC if not serving else METRIC + " [SERVING MODE: %d prompts per GPU and step, AR decode overlapped -- not the BASELINE configuration]" % P,
             "value": world * n_frames * args.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -495,6 +522,7 @@ def main():
                                    + (f"; streaming long video: {stream} chunks, {prefix} prefix latent frames pinned per later "
                                       f"chunk, {n_frames} frames" if stream else "")
                                    + (f"; fp8 e4m3 MFMA ({args.fp8_gemm} scaling) for the DiT qkv/dense/4h/4h->h linears" if args.fp8_gemm else "")
+                                   + ("; PLUS both text encoders per step (FLAN-T5-XXL over 64 tokens, T5-v1.1-XXL over 226), random-init at true shapes" if args.with_t5 else "")
                                    + (f"; SERVING MODE, not the BASELINE configuration: {P} prompts per GPU and step, AR decode of prompt "
                                       f"i+1 overlapped with the DiT loop of prompt i (generate_many)" if serving else ""),
                        "frames": n_frames, "height": 8 * d.latent_h, "width": 8 * d.latent_w,
@@ -522,7 +550,14 @@ def main():
         if world > 1 or use_dist:
             fps = [r["frames_per_s"] for r in reports]
             res["n_ranks_seen"] = dist.get_world_size()          # what RCCL itself says the job size was
+            # What a rank's GPU sustained right before its timed region, so that a scaling curve can be read net of the pool's
+            # GPU-to-GPU spread (+-5 % under the power cap): frames_per_s_normalised = frames_per_s x (mean MFMA-only rate of the
+            # job's GPUs / this GPU's) -- a rank on a slow GPU is not a scaling loss.  Each rank's own wall time, before the MAX.
+            cal = [r["calibration"] for r in reports]
+            mean_mfma = sum(c["mfma_tflops"] for c in cal) / len(cal)
             res["per_rank"] = {"frames_per_s_min": min(fps), "frames_per_s_max": max(fps), "frames_per_s": fps,
+                               "frames_per_s_normalised": [round(f * mean_mfma / c["mfma_tflops"], 4) for f, c in zip(fps, cal)],
+                               "calibration": cal, "calibration_mean_mfma_tflops": round(mean_mfma, 1),
                                "stage_seconds": [r["stage_seconds"] for r in reports], "cores_per_rank": [r["cores"] for r in reports]}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(PipelineConfig.full())

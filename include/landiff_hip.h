@@ -107,7 +107,8 @@ int ld_conv_cl_bf16_gn(const void* in_padded, const void* Wt, void* out, int64_t
 /* Which kernel ld_conv_cl_bf16 runs for a shape, without launching anything (no GPU needed): 0 = 128x128 two-stage,
  * 1 = 256x256 two-stage (32-bit element offsets: padded inputs up to 8 GiB), 2 = 256x256 8-phase (one raw buffer descriptor
  * over the padded input: inputs below 2 GiB only -- larger ones are routed to 1), negative = the shape is refused
- * (e.g. a padded input of 8 GiB or more), 3 = the narrow-output kernel (3x3x3, Cin 128, <= 4 output channels, H % 4 == 0,
+ * (e.g. a padded input of 8 GiB or more), 3 = never returned for a convolution (the register-staged 4-wave GEMM loop of the
+ * variants build), 5 = the narrow-output kernel (3x3x3, Cin 128, <= 4 output channels, H % 4 == 0,
  * W % 16 == 0 and a bias-only epilogue -- the VAE's conv_out: ld_conv_narrow.hip reads the input once instead of once per tap),
  * 4 = 512x128 8-phase (VARIANTS build with LD_GEMM_M512=1 only: 64 < Cout <= 128, 2048 <= K <= 4096, at least 256 such tiles,
  * padded input below 2 GiB -- a measured alternative for the VAE's 480x720 level).  All GEMM routes (0, 1, 2, 4) give bit-identical

@@ -45,7 +45,8 @@ __device__ __forceinline__ float lane32_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// v_max3_f32 by hand: plain fmaxf on MFMA outputs makes hipcc insert a canonicalising v_max per operand
+// v_max3_f32 by hand: plain fmaxf on MFMA outputs makes hipcc insert a canonicalising v_max per operand.  CAUTION: an asm statement
+// gets no hazard padding -- when the operands are MFMA results the caller provides the MFMA -> VALU wait states (ld_attn.hip)
 __device__ __forceinline__ float max3f(float a, float b, float c) {
   float r;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));

@@ -243,6 +243,10 @@ __global__ __launch_bounds__(256, WPS) void ld_attn_kernel(AttnParams p) {
     };
     if (need_mask) apply_mask();
     // ---- online softmax (per query column; lane and lane^32 share the row) ----
+    // max3f is an asm statement and its operands are MFMA results: hipcc pads the MFMA -> VALU read hazard only for instructions it
+    // knows, so the wait states go here, in a statement that names the accumulators (round 6: the same helper right behind its
+    // MFMAs in ld_attn_q64.hip's row-maximum pass read OLD accumulator values now and then -- run-to-run differences of one ulp)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));
     float mx = max3f(sacc[0][0], sacc[1][0], sacc[0][1]);
     mx = max3f(mx, sacc[1][1], sacc[0][2]);
 #pragma unroll

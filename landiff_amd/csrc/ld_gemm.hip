@@ -2260,6 +2260,9 @@ int launch_cfg(const GemmParams& p, bool conv, hipStream_t stream) {
   const int nbm = (p.M - p.m_begin + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   dim3 grid(nbm * nbn), block(NW * 64);
   const int epi = pick_epilogue(p);
+  // GroupNorm partials are summed per 64-row unit = two 32-row blocks of a wave tile (gemm_epilogue_core<GN>): a tile whose wave
+  // rows are an odd number of blocks compiles the sums out, and the caller's buffer would stay unwritten
+  LD_REQUIRE(!p.gn_part || (conv && (BM / WM / 32) % 2 == 0), "ld_conv_cl_bf16_gn: the %d x %d tile route cannot write GroupNorm partials", BM, BN);
   if (epi == EPI_QKV) {
     LD_REQUIRE(!conv, "ld_gemm_qkv_heads: not a convolution epilogue");
     return launch_kernel<ld_gemm_kernel<BM, BN, WM, WN, NSTAGE, false, EPI_QKV, true>>("ld_gemm_qkv_heads", grid, block, SMEM_QKV, stream, p);
@@ -2397,7 +2400,7 @@ long conv_input_bytes(const GemmParams& p) {
 constexpr long CONV_8P_MAX_BYTES = 0x7fffffffL;
 constexpr long CONV_MAX_BYTES = 1L << 33;
 
-enum { ROUTE_128_2STAGE = 0, ROUTE_256_2STAGE = 1, ROUTE_256_8PHASE = 2, ROUTE_256_W4R = 3, ROUTE_512_8PHASE = 4 };
+enum { ROUTE_128_2STAGE = 0, ROUTE_256_2STAGE = 1, ROUTE_256_8PHASE = 2, ROUTE_256_W4R = 3, ROUTE_512_8PHASE = 4, ROUTE_NARROW = 5 };   // (documented at ld_conv_route in landiff_hip.h)
 thread_local int g_last_route = -1;   // what launch() picked last ON THIS HOST THREAD (ld_conv_route's dry run reads it; the
                                       // pipeline runs launches from a helper thread too)
 
@@ -2415,6 +2418,10 @@ int launch(const GemmParams& p, bool conv, hipStream_t stream, bool dry_run = fa
   // 8 tile columns) do better with 4 rows x all 8 columns -- the whole W panel set stays in the XCD's L2 (ff2 1311 -> 1344 TFLOP/s)
   static bool group_forced = getenv("LD_GEMM_GROUP_M") != nullptr;
   const_cast<GemmParams&>(p).group_m = (!group_forced && (p.N + 255) / 256 <= 8) ? 4 : group_m;
+  if (p.gn_part) {      // (every conv route's epilogue is EPI_BIAS or EPI_GENERIC with 64-row units: the forms that sum partials)
+    const int e = pick_epilogue(p);
+    LD_REQUIRE(conv && (e == EPI_BIAS || e == EPI_GENERIC), "ld_conv_cl_bf16_gn: epilogue %d does not sum GroupNorm partials", e);
+  }
   // measured on MI355X (tools/gemm_dit_shapes.py): the 256x256 tile wins once the grid fills the chip twice over
   // (L2->LDS traffic halves); the 128x128 tile (2 workgroups/CU) is for small problems.  A 128x256-tile, two-workgroups-
   // per-CU form of the pipelined loop (epilogue of one workgroup under the main loop of the other) measured 10 % slower
@@ -2724,7 +2731,7 @@ LD_API int ld_conv_route(int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t C
   p.H = (int)H; p.W_ = (int)W; p.Hp = (int)(H + kH - 1); p.Wp = (int)(W + kW - 1);
   p.Cin = (int)Cin; p.kH = (int)kH; p.kW = (int)kW;
   if (conv_input_bytes(p) >= CONV_MAX_BYTES) return ld_set_error(LD_ERR_INVALID, "ld_conv_route: padded input beyond 8 GiB");
-  if (ld_conv_narrow_try(nullptr, nullptr, nullptr, nullptr, Cout, T, H, W, Cin, Cout, kT, kH, kW, true, nullptr, true) == 0) return 3;
+  if (ld_conv_narrow_try(nullptr, nullptr, nullptr, nullptr, Cout, T, H, W, Cin, Cout, kT, kH, kW, true, nullptr, true) == 0) return ROUTE_NARROW;
   g_last_route = -1;
   const int rc = launch(p, true, nullptr, /*dry_run=*/true);
   return rc ? rc : g_last_route;

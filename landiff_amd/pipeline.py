@@ -8,6 +8,7 @@ stages (no .npy round trip of the tokens, no model .cpu()/.cuda() shuffling, VAE
 from __future__ import annotations
 
 import os
+import sys
 import time
 from dataclasses import dataclass
 
@@ -378,16 +379,21 @@ def _parse_cpulist(text: str) -> list:
 
 
 def gpu_numa_nodes(sysfs: str = "/sys") -> tuple:
-    """(numa node of every visible AMD GPU in device order, {node: [cpus]}) read from sysfs WITHOUT touching HIP: the cards whose
-    PCI vendor is 0x1002 and that expose a compute hwmon, sorted by PCI address (the order HIP enumerates them in on one node),
-    filtered by a plain integer list in HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  A node of -1 or an
-    unreadable file gives None for that GPU."""
+    """(numa node of every visible AMD compute GPU in device order, {node: [cpus]}) read from sysfs WITHOUT touching HIP: the
+    cards whose PCI vendor is 0x1002 AND that expose a compute hwmon (hwmon*/freq1_input: display-only parts and iGPUs without an
+    sclk file are skipped), sorted by PCI address (the order the runtime enumerates them in on one node), then filtered the way the
+    runtimes compose their filters: ROCR_VISIBLE_DEVICES first (it hides devices from HIP), then HIP_VISIBLE_DEVICES or, if that
+    is unset, CUDA_VISIBLE_DEVICES (indices into what ROCR left).  Plain integer lists only: a UUID list, an index out of range
+    or an unreadable file yields an EMPTY list -- no claim about the order, and rank_core_plan falls back to the plain core cut
+    (as it does whenever the visible-card count is smaller than the local world).  A node of -1 gives None for that GPU."""
     import glob
     cards = []
     for dev in glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*/device")):
         try:
             if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
                 continue
+            if not glob.glob(os.path.join(dev, "hwmon", "hwmon*", "freq1_input")):
+                continue                        # not a compute part (no shader clock): HIP does not enumerate it
             pci = os.path.basename(os.path.realpath(dev))
             try:
                 node = int(open(os.path.join(dev, "numa_node")).read())
@@ -397,14 +403,19 @@ def gpu_numa_nodes(sysfs: str = "/sys") -> tuple:
         except OSError:
             continue
     cards = [n for _, n in sorted(set(cards))]
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+
+    def pick(cur, var):
         v = os.environ.get(var)
-        if v:
-            try:
-                cards = [cards[int(i)] for i in v.split(",")]
-            except (ValueError, IndexError):
-                cards = []                      # UUID lists etc.: no claim about the order
-            break
+        if not v:
+            return cur, False
+        try:
+            return [cur[int(i)] for i in v.split(",")], True
+        except (ValueError, IndexError):
+            return [], True                     # UUID lists etc.: no claim about the order
+    cards, _ = pick(cards, "ROCR_VISIBLE_DEVICES")
+    cards, used_hip = pick(cards, "HIP_VISIBLE_DEVICES")
+    if not used_hip:
+        cards, _ = pick(cards, "CUDA_VISIBLE_DEVICES")
     cpus = {}
     for n in {c for c in cards if c is not None}:
         try:
@@ -450,6 +461,11 @@ def pin_rank_cores(local_rank: int, local_world: int) -> list:
     except Exception:                            # sysfs layout surprises must never stop a run
         nodes, cpus = None, None
     mine = rank_core_plan(local_world, cores, nodes, cpus)[local_rank] if local_world > 1 else cores
+    if local_world > 1 and os.environ.get("LD_PIN_VERBOSE", "1") != "0":
+        numa = (nodes[local_rank] if nodes and len(nodes) >= local_world else None)
+        print(f"[landiff_amd] local rank {local_rank}/{local_world}: {len(mine)} host cores "
+              f"({mine[0]}..{mine[-1]})" + (f" on NUMA node {numa} of its GPU" if numa is not None else " (plain cut of the cpuset: GPU NUMA nodes unknown)"),
+              file=sys.stderr, flush=True) if mine else None
     if mine:
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, min(len(mine), torch.get_num_threads())))

@@ -66,6 +66,26 @@ def relative_buckets(n: int, num_buckets: int = 32, max_distance: int = 128) -> 
     return (ret + torch.where(is_small, a, large)).to(torch.int32)
 
 
+def random_state(cfg: T5Config, seed: int, device="cpu") -> dict:
+    """Seeded random weights in the HF T5EncoderModel layout at cfg's shapes (bench.py --with-t5, tools/t5_time.py: there is no
+    network for the released encoders): projections ~ N(0, 0.02), gains 1, embedding and bias table ~ N(0, 1)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rnd = lambda *shape, sc=0.02: (torch.randn(*shape, device=device, generator=g) * sc).to(BF)
+    inner = cfg.heads * cfg.d_kv
+    sd = {"shared.weight": rnd(cfg.vocab, cfg.d_model, sc=1.0), "encoder.final_layer_norm.weight": torch.ones(cfg.d_model, device=device),
+          "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight": rnd(cfg.num_buckets, cfg.heads, sc=1.0)}
+    for i in range(cfg.layers):
+        p = f"encoder.block.{i}.layer."
+        for nm, shp in (("0.SelfAttention.q.weight", (inner, cfg.d_model)), ("0.SelfAttention.k.weight", (inner, cfg.d_model)),
+                        ("0.SelfAttention.v.weight", (inner, cfg.d_model)), ("0.SelfAttention.o.weight", (cfg.d_model, inner)),
+                        ("1.DenseReluDense.wi_0.weight", (cfg.d_ff, cfg.d_model)), ("1.DenseReluDense.wi_1.weight", (cfg.d_ff, cfg.d_model)),
+                        ("1.DenseReluDense.wo.weight", (cfg.d_model, cfg.d_ff))):
+            sd[p + nm] = rnd(*shp)
+        sd[p + "0.layer_norm.weight"] = torch.ones(cfg.d_model, device=device)
+        sd[p + "1.layer_norm.weight"] = torch.ones(cfg.d_model, device=device)
+    return sd
+
+
 class T5EncoderRunner:
     def __init__(self, sd: dict, cfg: T5Config, device):
         assert cfg.d_kv == 64, "ld_t5_attn is written for head_dim 64 (T5-XXL / FLAN-T5-XXL)"

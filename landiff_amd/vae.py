@@ -66,6 +66,19 @@ class VAEDecoder:
         return (self.fuse_gn_stats and C % 8 == 0 and 0 < q <= 256 and 256 % q == 0 and q % self.cfg.gn_groups == 0
                 and self.cfg.gn_groups <= 64)
 
+    def workspace_bytes(self) -> int:
+        """HBM held by the conv input windows (self._win: 2T + 2 padded frames per causal conv) and the upsamplers' padded inputs
+        (self._padded).  They are allocated and zero-filled on first use and KEPT -- across chunks (the halo lives in them),
+        across decodes (no second zero-fill; a video's 6 chunks reuse them) and after a clear -- about 18 GB at 480 x 720, of the
+        288 GB this path is laid out for.  A caller that needs the memory back between videos calls release()."""
+        return sum(b.numel() * b.element_size() for b in list(self._win.values()) + list(self._padded.values()))
+
+    def release(self) -> None:
+        """Drop the window / padded-input buffers and any streaming state (the next decode allocates and zero-fills them again:
+        ~18 GB of fills at 480 x 720).  Not to be called between decode(stream_keep=True) and its continuation."""
+        self._win.clear(); self._win_pos.clear(); self._padded.clear(); self.cache = {}
+        torch.cuda.empty_cache()
+
     def _padded_buf(self, *shape):
         buf = self._padded.get(shape)
         if buf is None:

@@ -41,14 +41,21 @@ class OracleJobs:
         self.dir = tempfile.mkdtemp(prefix="ld_oracle_jobs_")
         self.procs = {}
 
-    def start(self, name):
+    def start(self, name, cpus=None):
+        """cpus: the host cores this child (and its torch threads) may use -- the session hands every job its own share of the
+        upper half of the cpuset and keeps the lower half for pytest itself, so that the oracle's OpenMP teams and the tests'
+        own CPU work do not fight over cores (oversubscribed spin-waiting teams made one test 5x slower)."""
         if name in self.procs:
             return
         out = os.path.join(self.dir, name + ".pt")
         log = open(os.path.join(self.dir, name + ".log"), "w")
         env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")     # CPU only: the checker never sees the GPU
-        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "oracle_jobs.py"), name, out], cwd=ROOT, env=env,
-                             stdout=log, stderr=subprocess.STDOUT)
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "oracle_jobs.py"), name, out]
+        pre = None
+        if cpus:
+            env["OMP_NUM_THREADS"] = str(len(cpus)); env["LD_ORACLE_JOB_THREADS"] = str(len(cpus))
+            pre = lambda: os.sched_setaffinity(0, cpus)
+        p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=log, stderr=subprocess.STDOUT, preexec_fn=pre)
         self.procs[name] = (p, out, log)
 
     def result(self, name, timeout=1700.0):
@@ -88,8 +95,25 @@ def pytest_collection_finish(session):
                 want += jobs
     if want and not session.config.option.collectonly:
         _JOBS = OracleJobs()
+        # core plan: pytest keeps the lower half of its cpuset, the jobs split the upper half by weight (the VAE decode is the long one)
+        weight = {"vae_two_chunks": 4, "llm_two_blocks_fp32": 2, "llm_two_blocks_bf16": 2, "dit_3p3_eps": 2}
+        cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+        plan = {}
+        if len(cpus) >= 4 * len(want):
+            mine, theirs = cpus[: len(cpus) // 2], cpus[len(cpus) // 2:]
+            tot, at = sum(weight.get(n, 1) for n in want), 0
+            for n in want:
+                share = max(2, len(theirs) * weight.get(n, 1) // tot)
+                plan[n] = set(theirs[at:at + share]) or None
+                at += share
+            os.sched_setaffinity(0, set(mine))
+            try:
+                import torch
+                torch.set_num_threads(max(1, min(len(mine), 64)))
+            except Exception:
+                pass
         for name in want:
-            _JOBS.start(name)
+            _JOBS.start(name, plan.get(name))
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -21,7 +21,10 @@ import torch
 
 
 def _threads(n):
-    torch.set_num_threads(max(1, min(n, os.cpu_count() or 1)))
+    """n threads unless the session handed this child its own cores (conftest.py: LD_ORACLE_JOB_THREADS = size of its cpuset)."""
+    given = int(os.environ.get("LD_ORACLE_JOB_THREADS", "0"))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(given or n, avail)))
 
 
 # ---- test_gpu_fullsize.py::test_vae_full_resolution_two_chunks_vs_oracle ----

@@ -308,10 +308,15 @@ def test_rank_core_plan_prefers_the_gpus_numa_node():
 
 def test_gpu_numa_nodes_reads_sysfs_without_hip(tmp_path, monkeypatch):
     from landiff_amd.pipeline import gpu_numa_nodes
-    for i, (pci, vendor, node) in enumerate([("0000:05:00.0", "0x1002", 0), ("0000:85:00.0", "0x1002", 1), ("0000:01:00.0", "0x1a03", -1)]):
+    # two compute GPUs, a BMC display chip of another vendor, and an AMD display-only part without a shader-clock hwmon (skipped)
+    for i, (pci, vendor, node, compute) in enumerate([("0000:05:00.0", "0x1002", 0, True), ("0000:85:00.0", "0x1002", 1, True),
+                                                      ("0000:01:00.0", "0x1a03", -1, False), ("0000:03:00.0", "0x1002", 0, False),
+                                                      ("0000:c5:00.0", "0x1002", 1, True)]):
         real = tmp_path / "devices" / "pci" / pci
         real.mkdir(parents=True)
         (real / "vendor").write_text(vendor + "\n"); (real / "numa_node").write_text(f"{node}\n")
+        if compute:
+            (real / "hwmon" / "hwmon0").mkdir(parents=True); (real / "hwmon" / "hwmon0" / "freq1_input").write_text("2400000000\n")
         card = tmp_path / "class" / "drm" / f"card{i}"
         card.mkdir(parents=True)
         os.symlink(real, card / "device")
@@ -321,9 +326,18 @@ def test_gpu_numa_nodes_reads_sysfs_without_hip(tmp_path, monkeypatch):
     for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         monkeypatch.delenv(v, raising=False)
     nodes, cpus = gpu_numa_nodes(str(tmp_path))
-    assert nodes == [0, 1] and cpus == {0: [0, 1, 2, 3, 8, 9], 1: [4, 5, 6, 7]}
+    assert nodes == [0, 1, 1] and cpus == {0: [0, 1, 2, 3, 8, 9], 1: [4, 5, 6, 7]}
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
     assert gpu_numa_nodes(str(tmp_path))[0] == [1]
+    # the filters compose: ROCR hides devices from HIP, HIP indexes what is left; CUDA_VISIBLE_DEVICES only when HIP's is unset
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,2"); monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")
+    assert gpu_numa_nodes(str(tmp_path))[0] == [1, 0]
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "0")
+    assert gpu_numa_nodes(str(tmp_path))[0] == [1, 0]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert gpu_numa_nodes(str(tmp_path))[0] == [0]
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "GPU-1234abcd")          # a UUID list: no claim -> the plain core cut
+    assert gpu_numa_nodes(str(tmp_path))[0] == []
 
 
 def test_save_video_tensor_fallback_writes_playable_avi(tmp_path):

@@ -211,3 +211,63 @@ def test_attn_dynamic_queue_survives_poisoned_counters_and_stream_exhaustion(cud
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+# ---- round 6: the fallback at the headline shape, priced by tools/attn_logit_sweep.py (profiles/r06_attn_logit_sweep.txt) ----
+def _sink_problem(cuda, T, frac, sink_key, seed=21):
+    """The DiT shape with ONE sink key per head whose logit q.k/8 is T for the queries of a fraction of the 256-row blocks
+    (tools/attn_logit_sweep.py; T < 0: every key's logit is ~T for those queries -- the underflow side of the window)."""
+    import math
+    B, H, N = 2, 30, 17776
+    q, k, vt = _qkv(cuda, B, H, N, seed=seed)
+    Npad = q.shape[2]
+    nblk = (Npad + 255) // 256
+    g = torch.Generator(device=cuda).manual_seed(seed + 1)
+    sel = torch.rand(B, H, nblk, device=cuda, generator=g) < frac
+    rows = sel[:, :, :, None].expand(B, H, nblk, 256).reshape(B, H, nblk * 256)[:, :, :Npad]
+    beta = math.sqrt(8.0 * abs(T))
+    if T > 0:
+        k[:, :, sink_key, :] = 0
+        k[:, :, sink_key, 0] = beta
+    else:
+        k[:, :, :N, 0] = beta
+    q[:, :, :, 0] = torch.where(rows, torch.full_like(q[:, :, :, 0], beta if T > 0 else -beta), q[:, :, :, 0])
+    q[:, :, N:] = 0
+    return q, k, vt, sel, B, H, N
+
+
+def _err_vs_fp32(q, k, vt, out, N, heads):
+    worst = 0.0
+    for b, h in heads:
+        s = (q[b, h, :N].float() @ k[b, h, :N].float().T) * 0.125
+        ref = torch.softmax(s, dim=1) @ vt[b, h, :, :N].float().T
+        got = out[b, :, h * 64:(h + 1) * 64].float()
+        assert torch.isfinite(got).all(), (b, h)
+        worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
+    return worst
+
+
+@pytest.mark.parametrize("T,frac,sink_key", [(90, 0.1, 0), (120, 1.0, 0), (90, 0.3, 17775), (-70, 0.2, 0), (70, 1.0, 0)])
+def test_attn_fallback_at_the_dit_shape_with_sink_keys(cuda, monkeypatch, T, frac, sink_key):
+    """The pulled launch at the headline shape on data that drives the max-free fast pass out of its window ([2^-80, 2^110] for a
+    row's denominator: a row maximum of q.k/8 beyond ~76, or every logit below ~-55): the affected 256-row blocks re-run through
+    the running-max pass inside the launch.  Sink at key 0 / at the last key / the underflow side / a sink INSIDE the window (70:
+    no block re-runs).  Against torch fp32 on heads with and without affected blocks, run to run identical, and the same bits as
+    the one-workgroup-per-block dispatch (LD_ATTN_DYN=0: same per-block code)."""
+    from landiff_amd import ops
+    q, k, vt, sel, B, H, N = _sink_problem(cuda, T, frac, sink_key)
+    out = torch.full((B, N, H * 64), float("nan"), device=cuda, dtype=torch.bfloat16)
+    ops.attn_fwd(q, k, vt, out, N, N, 0.125)
+    assert _last_kernel() == "ld_attn_q64_dyn_kernel"
+    # a logit of ~100 in bf16 operands carries an absolute error of ~0.4: the sink rows' probabilities move by tens of per cent of
+    # tiny tails; the output (dominated by the sink's V row) stays within a few bf16 ulps of the range
+    err = _err_vs_fp32(q, k, vt, out, N, [(0, 0), (1, 17), (1, 29)])
+    assert err < 3e-2, err
+    out2 = torch.full_like(out, float("nan"))
+    ops.attn_fwd(q, k, vt, out2, N, N, 0.125)
+    assert torch.equal(out, out2)
+    monkeypatch.setenv("LD_ATTN_DYN", "0")
+    ref = torch.full_like(out, float("nan"))
+    ops.attn_fwd(q, k, vt, ref, N, N, 0.125)
+    assert _last_kernel() == "ld_attn_q64_kernel"
+    assert torch.equal(out, ref)

@@ -81,7 +81,7 @@ def test_conv_narrow_output_route(cuda, monkeypatch, T, H, W, Cout):
     rounding of the output, not bit for bit; the kernel itself repeats exactly; columns past Cout of the output rows stay untouched."""
     from landiff_amd import _lib, ops
     Cin = 128
-    assert _lib.load().ld_conv_route(T, H, W, Cin, Cout, 3, 3, 3) == 3
+    assert _lib.load().ld_conv_route(T, H, W, Cin, Cout, 3, 3, 3) == 5      # ROUTE_NARROW
     g = torch.Generator(device="cpu").manual_seed(5)
     x = torch.randn(1, Cin, T + 2, H, W, generator=g).to(cuda, torch.bfloat16)
     w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.05).to(cuda, torch.bfloat16)
@@ -102,7 +102,7 @@ def test_conv_narrow_output_route(cuda, monkeypatch, T, H, W, Cout):
     d = (out.float() - gemm_route.float()).abs()
     assert d.max().item() <= 2.0 ** -7 * ref.abs().max().item() and (d > 0).float().mean().item() < 0.2      # at most one bf16 step, on few elements
     # shapes outside the narrow kernel keep the GEMM route
-    assert _lib.load().ld_conv_route(T, H + 1, W, Cin, Cout, 3, 3, 3) != 3 and _lib.load().ld_conv_route(T, H, W, 256, Cout, 3, 3, 3) != 3
+    assert _lib.load().ld_conv_route(T, H + 1, W, Cin, Cout, 3, 3, 3) != 5 and _lib.load().ld_conv_route(T, H, W, 256, Cout, 3, 3, 3) != 5
 
 
 @pytest.mark.parametrize("T,H,W,Cin,Cout,route,resid", [(2, 12, 20, 64, 128, 0, True), (1, 8, 8, 64, 512, 0, False),

@@ -235,6 +235,10 @@ def test_llm_teacher_forced_logits_and_sampler(cuda, setup):
     # no agreement quota: audit() has accounted for every single flip (a flip it cannot explain fails the test), and the ids that
     # did not flip are exactly the oracle's
     assert n_cmp == n_vis and int((ref_codes.reshape(-1) != codes.cpu()).sum()) <= len(flips), (n_cmp, len(flips))
+    # ... and a loose aggregate bound beside the per-flip audit: a SYSTEMATIC logit bias that stays inside every step's measured
+    # difference could flip many draws and still pass audit(); rounding noise is zero-mean and flips a few per cent of a flat
+    # random model's draws (measured: 2-6 of 176).  More than 10 % of the compared steps is not noise.
+    assert len(flips) <= max(4, n_cmp // 10), (len(flips), n_cmp)
     # unguided decode (cfg=0, the dataclass default): first-step logits equal the oracle's batch-1 prefill
     logu = []
     genu = torch.Generator(device=cuda); genu.manual_seed(2)

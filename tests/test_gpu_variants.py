@@ -311,3 +311,8 @@ def test_bench_rccl_path_single_rank(cuda, launcher):
     assert res["roofline"]["bound"] == "mfma" and res["roofline"]["frac"] == pytest.approx(res["roofline"]["achieved"] / res["roofline"]["peak"], abs=1e-3)
     assert res["calibration"]["mfma_tflops"] > 100 and res["calibration"]["hbm_gbs"] > 500
     assert len(res["per_rank"]["frames_per_s"]) == 1
+    # every rank calibrates its own GPU (round 6): a future scaling curve can be read net of the pool's GPU-to-GPU spread
+    pr = res["per_rank"]
+    assert len(pr["calibration"]) == 1 and pr["calibration"][0]["mfma_tflops"] == res["calibration"]["mfma_tflops"]
+    assert pr["calibration"][0]["hbm_gbs"] > 500 and "timed_region_sclk_mhz" in pr["calibration"][0]
+    assert pr["frames_per_s_normalised"] == pytest.approx(pr["frames_per_s"], rel=1e-3)      # one rank: the mean is its own rate

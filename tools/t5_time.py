@@ -1,23 +1,11 @@
-"""T5-XXL-size encoder (random weights) on the MI355X kernels: time per prompt at 226 and 512 tokens."""
+"""T5-XXL-size encoder (random weights) on the MI355X kernels: time per prompt at 64, 226 and 512 tokens."""
 import sys, time, torch
 sys.path.insert(0, ".")
-from landiff_amd.t5 import T5Config, T5EncoderRunner
+from landiff_amd.t5 import T5Config, T5EncoderRunner, random_state
 cfg = T5Config()
 dev = torch.device("cuda:0")
-g = torch.Generator(device=dev).manual_seed(0)
-def rnd(*s, sc=0.02): return (torch.randn(*s, device=dev, generator=g) * sc).to(torch.bfloat16)
-sd = {"shared.weight": rnd(cfg.vocab, cfg.d_model, sc=1.0), "encoder.final_layer_norm.weight": torch.ones(cfg.d_model),
-      "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight": rnd(cfg.num_buckets, cfg.heads, sc=1.0)}
+run = T5EncoderRunner(random_state(cfg, 0, dev), cfg, dev)
 inner = cfg.heads * cfg.d_kv
-for i in range(cfg.layers):
-    p = f"encoder.block.{i}.layer."
-    for nm, shp in (("0.SelfAttention.q.weight", (inner, cfg.d_model)), ("0.SelfAttention.k.weight", (inner, cfg.d_model)),
-                    ("0.SelfAttention.v.weight", (inner, cfg.d_model)), ("0.SelfAttention.o.weight", (cfg.d_model, inner)),
-                    ("1.DenseReluDense.wi_0.weight", (cfg.d_ff, cfg.d_model)), ("1.DenseReluDense.wi_1.weight", (cfg.d_ff, cfg.d_model)),
-                    ("1.DenseReluDense.wo.weight", (cfg.d_model, cfg.d_ff))):
-        sd[p + nm] = rnd(*shp)
-    sd[p + "0.layer_norm.weight"] = torch.ones(cfg.d_model); sd[p + "1.layer_norm.weight"] = torch.ones(cfg.d_model)
-run = T5EncoderRunner(sd, cfg, dev)
 for n in (64, 226, 512):
     ids = torch.randint(0, cfg.vocab, (n,), device=dev)
     run.encode(ids); torch.cuda.synchronize()
