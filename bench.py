@@ -425,7 +425,7 @@ def main():
     n_frames = out[0].shape[1]
     stage_s = {k: v / args.steps for k, v in pipe.timings.items()}
     gemm_step_s = None
-    if rank == 0 and not args.fp8_gemm and not stream and P == 1:
+    if rank == 0 and P == 1 and not args.tiny and (not stream or args.fp8_gemm):      # (bf16 streaming runs: the headline line carries the figure)
         # one more step OUTSIDE the timed region with HIP events around every large DiT Linear (~20 k event records per video
         # would otherwise sit in the headline number)
         keep_t, keep_a, keep_o = pipe.timings, pipe.dit.attn_events, pipe.dit.overlap
@@ -480,15 +480,31 @@ def main():
         stages["dit_attention"]["what"] = ("the kernel's own duration (launches that run alone) x all launches of a step: GPU time, not wall time -- "
                                            "overlapped launches take longer on the wall (avg_launch_ms_all_incl_overlapped)")
         gev = pipe.dit.gemm_events
-        if gev and not args.fp8_gemm:          # (the e4m3 linears are not bracketed: only the bf16 control zero-linears would be counted)
-            g_s = sum(a.elapsed_time(b) for a, b, _ in gev) * 1e-3
-            g_fl = sum(f for _, _, f in gev)
-            g_ach = g_fl / g_s / 1e12
-            stages["dit_gemm"] = {"bound": "mfma", "achieved": round(g_ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(g_ach / peak, 4),
-                                  "seconds_per_step": round(g_s, 3), "launches": len(gev),
-                                  "what": "HIP events around every qkv / dense / 4h / 4h->h Linear and control zero-linear of the DiT loop "
-                                          "(2 M N K each; 3.145 TFLOP per layer-call + 0.262 per control layer), tail launches included; "
-                                          "collected in ONE extra, serial step after the timed region (the headline loop carries no GEMM events)"}
+        if gev:
+            # events of the e4m3 linears carry (flops, "mx"), the bf16 ones (all of them in the headline configuration; the control
+            # zero-linears under --fp8-gemm) plain flops
+            split = {"bf16": [0.0, 0.0, 0], "mx": [0.0, 0.0, 0]}
+            for a, b, f in gev:
+                kind = "bf16"
+                if isinstance(f, tuple):
+                    f, kind = f
+                acc = split[kind]
+                acc[0] += a.elapsed_time(b) * 1e-3; acc[1] += f; acc[2] += 1
+            what = ("HIP events around every qkv / dense / 4h / 4h->h Linear and control zero-linear of the DiT loop "
+                    "(2 M N K each; 3.145 TFLOP per layer-call + 0.262 per control layer), tail launches included; "
+                    "collected in ONE extra, serial step after the timed region (the headline loop carries no GEMM events)")
+            if split["bf16"][2]:
+                g_s, g_fl, n_ = split["bf16"]
+                g_ach = g_fl / g_s / 1e12
+                stages["dit_gemm"] = {"bound": "mfma", "achieved": round(g_ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(g_ach / peak, 4),
+                                      "seconds_per_step": round(g_s, 3), "launches": n_,
+                                      "what": what if not args.fp8_gemm else "the bf16 linears left under --fp8-gemm (control zero-linears); " + what}
+            if split["mx"][2]:
+                g_s, g_fl, n_ = split["mx"]
+                g_ach = g_fl / g_s / 1e12
+                stages["dit_gemm_mxfp8"] = {"bound": "mfma", "achieved": round(g_ach, 1), "peak": 2 * peak, "unit": "TFLOP/s", "frac": round(g_ach / (2 * peak), 4),
+                                            "seconds_per_step": round(g_s, 3), "launches": n_,
+                                            "what": "the e4m3 (MXFP8) qkv / dense / 4h / 4h->h linears against the dense MX-fp8 MFMA peak (~5 PFLOP/s); " + what}
         if "detokenize" in stage_s and not stream and P == 1 and not args.tiny:
             dtf = detok_tflop(cfg)
             stages["detokenize"] = {"bound": "mfma", "achieved": round(dtf / stage_s["detokenize"], 1), "peak": peak, "unit": "TFLOP/s",

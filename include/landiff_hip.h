@@ -26,8 +26,8 @@ extern "C" {
  * argument, ld_gemm_qkv_heads / ld_llm_sample_advance / ld_groupnorm_stats_blocks / ld_attn_last_kernel were added).  A caller
  * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does).
  * 6: ld_reset and ld_attn_queue_poke were added.  7: ld_conv_cl_bf16_gn, ld_conv_gn_partials_size and
- * ld_groupnorm_stats_from_conv were added. */
-#define LD_ABI_VERSION 7
+ * ld_groupnorm_stats_from_conv were added.  8: ld_gemm_qkv_heads_mxfp8 was added. */
+#define LD_ABI_VERSION 8
 
 int ld_version(void);
 const char* ld_last_error(void);
@@ -144,12 +144,20 @@ int ld_quantize_mxfp8(const void* x, int64_t ldx, void* q, int64_t ldq, void* sc
                       int64_t K, void* stream);
 
 /* out = epilogue(sum over blocks of 2^(sa-127) 2^(sw-127) sum_{k in block} A8[m][k] W8[n][k]): the block scales are
- * applied by v_mfma_scale_f32_32x32x64_f8f6f4 itself.  scales_a [K/128][M][4], scales_w [K/128][N][4] contiguous. */
+ * applied by the MFMA itself (v_mfma_scale_f32_16x16x128_f8f6f4 on the persistent two-phase loop since round 6).  scales_a [K/128][M][4], scales_w [K/128][N][4] contiguous. */
 int ld_gemm_mxfp8(const void* A8, int64_t lda, const void* scales_a, const void* W8, const void* scales_w, void* out,
                   int64_t ldo, void* out_scales, int64_t ldos, int64_t M, int64_t N, int64_t K,
                   const ld_epilogue_t* epi, void* stream);
 /* (out_scales != NULL: the output is itself MXFP8 -- out = e4m3 [M][ldo bytes], out_scales [N/128][ldos >= M][4] -- for the
  * bias + GELU-tanh epilogue of dense_h_to_4h, whose result only feeds the next MXFP8 GEMM.) */
+
+/* ld_gemm_qkv_heads on MXFP8 operands (BASELINE configs[4]; round 6): the DiT's qkv Linear with QK-LayerNorm, head split and V
+ * transpose in its epilogue, A8 [M][lda bytes] / W8 [3*heads*64][K] e4m3 codes with scales_a [K/128][M][4], scales_w
+ * [K/128][3*heads*64][4].  Same outputs and shape rules as ld_gemm_qkv_heads; K % 128 == 0.  Reference sites: as ld_gemm_qkv_heads. */
+int ld_gemm_qkv_heads_mxfp8(const void* A8, int64_t lda, const void* scales_a, const void* W8, const void* scales_w,
+                            const void* bias, int64_t M, int64_t K, void* Q, void* Kh, void* Vt, int64_t B, int64_t Ntok,
+                            int64_t heads, int64_t Npad, const void* q_w, const void* q_b, const void* k_w, const void* k_b,
+                            float eps, void* stream);
 
 /* ld_layernorm (+ AdaLN modulate) with MXFP8 output: exactly ld_layernorm's bf16 result, quantised where it is produced
  * (q e4m3 [rows][ldq bytes], scales [D/128][lds >= rows][4]) for the MXFP8 GEMM that consumes it.  bf16 input, D % 128 == 0. */

@@ -44,7 +44,7 @@ class LlmLayer(Structure):
 
 
 _lib = None
-ABI_VERSION = 7          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
+ABI_VERSION = 8          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
 
 I64 = c_int64
 I32 = c_int32
@@ -77,6 +77,7 @@ SIGNATURES: dict[str, list] = {
     "ld_quantize_mxfp8": [P, I64, P, I64, P, I64, I64, I64, P],
     "ld_layernorm_mxfp8": [P, I64, P, P, P, I64, P, I64, I64, I64, c_float, P, I64, I64, I64, I64, I64, I64, I64, P],
     "ld_gemm_mxfp8": [P, I64, P, P, P, P, I64, P, I64, I64, I64, I64, P, P],
+    "ld_gemm_qkv_heads_mxfp8": [P, I64, P, P, P, P, I64, I64, P, P, P, I64, I64, I64, I64, P, P, P, P, c_float, P],
     "ld_feature_norm_cl": [P, I32, P, P, P, I64, I64, I64, P],
     "ld_feature_denorm": [P, P, P, P, I64, I64, P],
     "ld_vq_nearest": [P, I64, P, P, I64, I64, I64, P],

@@ -35,6 +35,7 @@ int ld_conv_narrow_try(const void* in_padded, const void* w, const void* bias, v
 namespace {
 
 constexpr int BK = 64;
+typedef int i32x8_t __attribute__((ext_vector_type(8)));      // operand of the f8f6f4 MFMAs
 constexpr int CW_STRIDE = 68;                    // fp32 row stride of the epilogue staging tile (64 cols + pad)
 
 struct GemmParams {
@@ -1704,6 +1705,269 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_n128_kernel(GemmParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// MXFP8 operands on the persistent loop of ld_gemm8p_kernel (round 6; BASELINE configs[4]).  A K-tile of 128 e4m3 elements is a
+// 128-byte row, exactly the bf16 kernel's 64-element row: the same eight 16 KB half-tile slots, the same per-lane LDS-DMA offsets
+// (in bytes), the same XOR swizzle, the same two phases of the K-tile with the two wave rows one barrier apart, the same persistent
+// tile walk, next-tile request from inside the epilogue and the same epilogues (incl. the fused qkv head split and the MXFP8-writing
+// GELU epilogue), because v_mfma_scale_f32_16x16x128_f8f6f4 leaves its 16 x 16 block in the registers of v_mfma_f32_16x16x32_bf16.
+// What changes:
+//   * one MFMA per accumulator block and K-tile (32 per wave, ~32 cycles each) instead of two; its 32-byte operand is the PAIR of
+//     16-byte fragments the bf16 loop reads for its two k-steps -- lane (r, g) holds k = 16 g .. + 16 and 64 + 16 g .. + 16 of row r
+//     (tools/probe/fp8_mfma16_layout.hip: layout D1) -- so the fragment reads are the bf16 kernel's, address for address;
+//   * block scales: one E8M0 byte per row and 32 K elements, [K / 128][rows][4] in memory (ld_quantize_mxfp8).  A K-tile's 256 + 256
+//     row dwords travel by 4-byte LDS-DMA next to A_0 / B_0 (waves 0-3: A rows, 4-7: W rows) into a 2 KB strip per K-tile buffer; in
+//     P0 a lane reads the dwords of its 8 + 4 block rows and keeps byte g (the hardware takes block g's scale from lane group g:
+//     scale layout S0) of each, packed four to a register -- the MFMA's op_sel picks the byte.
+// LDS: [K-tile buffer 0: 64 KB][scale strips: 2 x 2 KB][K-tile buffer 1: 64 KB]; the epilogue staging at the end of the 160 KB stays
+// clear of buffer 0 and the strips.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void ld_gemm8p_mx_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, KB = 128;             // KB: bytes (= e4m3 elements) of K per tile
+  constexpr int SLOT = 128 * 128, KBUF = 4 * SLOT;
+  constexpr int SC_OFF = KBUF, SC_BYTES = 4096;           // [buffer][A rows 1 KB | W rows 1 KB]
+  constexpr int BUF1 = KBUF + SC_BYTES;                   // byte offset of K-tile buffer 1
+  constexpr int EPI_BYTES = (EPI == EPI_QKV) ? 8 * QKV_REGION : 8 * 32 * CW_STRIDE * 4;
+  constexpr int EPI_OFF = (LD_LDS_TOTAL - EPI_BYTES) & ~15;
+  constexpr bool PREFETCH = EPI_OFF >= BUF1 && EPI != EPI_QKV;
+  constexpr bool SWAPACC = EPI != EPI_QKV;
+  static_assert(BUF1 + KBUF <= LD_LDS_TOTAL, "LDS layout");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int ntiles = nbm * nbn;
+  const int gm_sz = p.group_m;
+  auto tile_origin = [&](int v, int& m0, int& n0) {       // (ld_gemm8p_kernel's)
+    const int bid = xcd_remap(v, ntiles);
+    const int per_group = gm_sz * nbn;
+    const int group = bid / per_group, in_group = bid - group * per_group;
+    const int first_m = group * gm_sz;
+    const int rows_here = (nbm - first_m) < gm_sz ? (nbm - first_m) : gm_sz;
+    m0 = (first_m + in_group % rows_here) * BM;
+    n0 = (in_group / rows_here) * BN;
+  };
+  const auto clip = [](long v) { return (int)(v < 0x7fffffffL ? v : 0x7fffffffL); };
+  const long ldab = p.lda, ldwb = p.K;                    // row strides in bytes
+  struct Src { const unsigned char* a; const unsigned char* w; const unsigned char* s; int a_bytes, w_bytes, s_bytes; };
+  const bool a_wave = wave < 4;                           // which operand's scale dwords this wave fetches
+  const long srows = a_wave ? p.M : p.N;
+  auto tile_src = [&](int m0, int n0) {
+    Src s;
+    s.a = (const unsigned char*)p.A + (long)m0 * ldab;
+    s.w = (const unsigned char*)p.W + (long)n0 * ldwb;
+    s.a_bytes = clip((long)(p.M - m0) * ldab);
+    s.w_bytes = clip((long)(p.N - n0) * ldwb);
+    const long so = a_wave ? m0 : n0;
+    s.s = (a_wave ? p.mx_a : p.mx_w) + so * 4;            // rows past M / N read as zero scale bytes (their products are never stored)
+    s.s_bytes = clip(((long)(p.K >> 7) * srows - so) * 4);
+    return s;
+  };
+  uint32_t offA[2][2], offW[2][2];                        // [half][piece] byte offsets (the bf16 kernel's rows and swizzle)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = wave * 16 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int tm = (lr >> 6) * 128 + h * 64 + (lr & 63);
+      const int tn = (lr >> 5) * 64 + h * 32 + (lr & 31);
+      offA[h][i] = (uint32_t)((long)tm * ldab + chunk * 16);
+      offW[h][i] = (uint32_t)((long)tn * ldwb + chunk * 16);
+    }
+  }
+  const uint32_t offS = (uint32_t)(((wave & 3) * 64 + lane) * 4);     // this lane's row dword of the strip
+  const int sslab = (int)(srows * 4);                     // bytes between consecutive K-tiles' scale slabs
+  const int nk = p.K / KB;
+  char* const my_piece = smem + wave * 2048;
+  Src src;
+  auto stage_a = [&](const Src& s, auto bufc, auto hc, int kt) {
+    constexpr int OFF = (decltype(bufc)::value ? BUF1 : 0) + decltype(hc)::value * SLOT;
+    stage_pieces<OFF>((const bf16_t*)s.a, s.a_bytes, my_piece, offA[decltype(hc)::value][0], offA[decltype(hc)::value][1], kt * KB);
+  };
+  auto stage_w = [&](const Src& s, auto bufc, auto gc, int kt) {
+    constexpr int OFF = (decltype(bufc)::value ? BUF1 : 0) + (2 + decltype(gc)::value) * SLOT;
+    stage_pieces<OFF>((const bf16_t*)s.w, s.w_bytes, my_piece, offW[decltype(gc)::value][0], offW[decltype(gc)::value][1], kt * KB);
+  };
+  auto stage_s = [&](const Src& s, auto bufc, int kt) {     // 256 B per wave: the 64 row dwords (waves 0-3: A rows, 4-7: W rows)
+    constexpr int OFF = SC_OFF + decltype(bufc)::value * 2048;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)s.s, 0, s.s_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + OFF + wave * 256), 4, offS, kt * sslab, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto stage_ktile0 = [&](const Src& s) {                 // 9 LDS-DMA instructions per wave
+    stage_a(s, I0{}, I0{}, 0); stage_w(s, I0{}, I0{}, 0); stage_s(s, I0{}, 0); stage_w(s, I0{}, I1{}, 0); stage_a(s, I0{}, I1{}, 0);
+  };
+
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {                        // 16-byte chunk g and chunk 4 + g of the row: the operand's two halves
+    const int c = (ks * 4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7);
+    rdA[ks] = (wr * 64 + (lane & 15)) * 128 + (c << 4);
+    rdB[ks] = (wc * 32 + (lane & 15)) * 128 + (c << 4);
+  }
+  const int sh8 = (lane >> 4) * 8;                        // this lane group's scale byte inside a row dword
+  f32x4_t acc[8][4];
+  u32x4_t a[4][2], b0[2][2], b1[2][2];
+  uint32_t sA[2] = {0u, 0u}, sB = 0u;                     // packed scale bytes: sA[h] byte i = block row i of half h; sB byte 2 g + j
+  auto read_a = [&](auto bufc, auto hc) {
+    constexpr int OFF = (decltype(bufc)::value ? BUF1 : 0) + decltype(hc)::value * SLOT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[i][ks] = *(const u32x4_t*)(smem + rdA[ks] + OFF + i * 2048);
+  };
+  auto read_b = [&](auto bufc, auto gc, u32x4_t (&b)[2][2]) {
+    constexpr int OFF = (decltype(bufc)::value ? BUF1 : 0) + (2 + decltype(gc)::value) * SLOT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b[j][ks] = *(const u32x4_t*)(smem + rdB[ks] + OFF + j * 2048);
+  };
+  auto read_scales = [&](auto bufc) {
+    const char* sc = smem + SC_OFF + decltype(bufc)::value * 2048;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t pk = 0u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t d = *(const uint32_t*)(sc + (wr * 128 + h * 64 + i * 16 + (lane & 15)) * 4);
+        pk |= ((d >> sh8) & 0xffu) << (8 * i);
+      }
+      sA[h] = pk;
+    }
+    uint32_t pk = 0u;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t d = *(const uint32_t*)(sc + 1024 + (wc * 64 + g * 32 + j * 16 + (lane & 15)) * 4);
+        pk |= ((d >> sh8) & 0xffu) << (8 * (2 * g + j));
+      }
+    sB = pk;
+  };
+  bool wave_live = true;
+  auto frag = [](const u32x4_t (&f)[2]) {
+    return (i32x8_t){(int)f[0][0], (int)f[0][1], (int)f[0][2], (int)f[0][3], (int)f[1][0], (int)f[1][1], (int)f[1][2], (int)f[1][3]};
+  };
+  auto mma1 = [&](auto hc, auto gc, u32x4_t (&b)[2][2]) {   // 8 MFMAs: the 64 x 32 quadrant (h, g)
+    constexpr int H = decltype(hc)::value, G = decltype(gc)::value;
+    auto one = [&](auto ic, auto jc) {                      // (op_sel is an immediate: block indices as types)
+      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+      if constexpr (SWAPACC)
+        acc[H * 4 + i][G * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(frag(b[j]), frag(a[i]), acc[H * 4 + i][G * 2 + j], 0, 0, 2 * G + j, sB, i, sA[H]);
+      else
+        acc[H * 4 + i][G * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(frag(a[i]), frag(b[j]), acc[H * 4 + i][G * 2 + j], 0, 0, i, sA[H], 2 * G + j, sB);
+    };
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    one(I0{}, I0{}); one(I0{}, I1{}); one(I1{}, I0{}); one(I1{}, I1{});
+    one(I2{}, I0{}); one(I2{}, I1{}); one(I3{}, I0{}); one(I3{}, I1{});
+  };
+  auto mma2 = [&](auto hc, auto g0c, u32x4_t (&bA)[2][2], auto g1c, u32x4_t (&bB)[2][2]) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_live) {
+      __builtin_amdgcn_s_setprio(1);
+      mma1(hc, g0c, bA);
+      mma1(hc, g1c, bB);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // LDS-DMA instructions per wave: a half-tile = 2, a scale strip = 1.  In flight on entry of P0(kt), oldest first:
+  // A_1(kt) [2], then A_0 / B_0 / S(kt + 1) [5]
+  auto ktile = [&](auto bufc, int kt) {
+    constexpr int B = decltype(bufc)::value;
+    using Bc = std::integral_constant<int, B>;
+    using Nc = std::integral_constant<int, B ^ 1>;
+    // P0
+    read_b(Bc{}, I0{}, b0);
+    read_b(Bc{}, I1{}, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(Bc{}, I0{});
+    read_scales(Bc{});
+    if (kt + 1 < nk) {
+      stage_w(src, Nc{}, I1{}, kt + 1); stage_a(src, Nc{}, I1{}, kt + 1);
+      asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");   // A_1(kt) has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    bar(); mma2(I0{}, I0{}, b0, I1{}, b1); bar();
+    // P1.  In flight: A_0 / B_0 / S(kt + 1) [5], B_1 / A_1(kt + 1) [4]
+    read_a(Bc{}, I1{});
+    if (kt + 2 < nk) {
+      stage_a(src, Bc{}, I0{}, kt + 2); stage_w(src, Bc{}, I0{}, kt + 2); stage_s(src, Bc{}, kt + 2);
+      asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");   // A_0 / B_0 / S / B_1 of K-tile kt + 1 have landed
+    } else if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    bar(); mma2(I1{}, I1{}, b1, I0{}, b0); bar();
+  };
+
+  bool k0_staged = false;
+  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+    int m0, n0;
+    tile_origin(v, m0, n0);
+    src = tile_src(m0, n0);
+    wave_live = n0 + wc * 64 < p.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    if (!k0_staged) stage_ktile0(src);
+    if (nk > 1) {
+      stage_a(src, I1{}, I0{}, 1); stage_w(src, I1{}, I0{}, 1); stage_s(src, I1{}, 1);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    if (wr == 1) bar();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(I0{}, kt);
+      ktile(I1{}, kt + 1);
+    }
+    if (kt < nk) ktile(I0{}, kt);
+    if (wr == 0) bar();
+    __syncthreads();
+
+    const int vn = v + gridDim.x;
+    bool hooked = false;
+    Src nsrc = src;
+    k0_staged = false;
+    if (PREFETCH && vn < ntiles) {
+      int m1, n1;
+      tile_origin(vn, m1, n1);
+      nsrc = tile_src(m1, n1);
+      k0_staged = true;
+    }
+    auto hook = [&]() {
+      if (!hooked && k0_staged) stage_ktile0(nsrc);
+      hooked = true;
+    };
+    if constexpr (EPI == EPI_QKV) qkv_epilogue16<4>(p, acc, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
+    else gemm_epilogue16<4, EPI, 4, SWAPACC, decltype(hook)&>(p, acc, 0, smem + EPI_OFF, wave, lane, m0 + wr * 128, n0 + wc * 64, hook);
+    hook();
+    if (vn < ntiles) __syncthreads();
+  }
+}
+
 #ifdef LD_VARIANTS   // measured alternatives, not in the shipped library (build.sh: LD_BUILD_VARIANTS=1)
 // ------------------------------------------------------------------------------------------------
 // Software-pipelined main loop (round 4; LD_GEMM_SP=1): the 256 x 256 x 64 tile / 8 waves (2 x 4, 128 x 64 per wave) /
@@ -1921,7 +2185,6 @@ __global__ __launch_bounds__(512, 2) void ld_gemm_sp_kernel(GemmParams p) {
 // The accumulator is dequantised in registers -- acc * scale_a[row] * scale_w[col] -- and then takes the ordinary
 // epilogues (bias / GELU / gated residual).
 // ------------------------------------------------------------------------------------------------
-typedef int i32x8_t __attribute__((ext_vector_type(8)));
 
 // MX = true: MXFP8 operands -- the per-32-element E8M0 scales go into the MFMA itself (one byte per lane and operand: the
 // lane's row and its 32-deep half of the 64-deep step), fetched as one dword per row and 128-deep K-tile straight into
@@ -2533,7 +2796,32 @@ int fill_epilogue(GemmParams& p, const ld_epilogue_t* e) {
   return LD_OK;
 }
 
+// MXFP8 on the persistent two-phase loop (ld_gemm8p_mx_kernel): every tile of the raster, one workgroup per CU walking it
+int launch_8p_mx(const GemmParams& p, hipStream_t stream) {
+  const long ntiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0 || (ncu & 7)) ncu = 256;
+  }
+  const_cast<GemmParams&>(p).group_m = (p.N + 255) / 256 <= 8 ? 4 : 8;      // (launch()'s raster rule)
+  dim3 grid((unsigned)(ntiles > ncu ? ncu : ntiles)), block(512);
+  constexpr int SMEM = LD_LDS_TOTAL;
+  switch (pick_epilogue(p)) {
+    case EPI_QKV: return launch_kernel<ld_gemm8p_mx_kernel<EPI_QKV>>("ld_gemm_qkv_heads_mxfp8", grid, block, SMEM, stream, p);
+    case EPI_BIAS: return launch_kernel<ld_gemm8p_mx_kernel<EPI_BIAS>>("ld_gemm_mxfp8(8p)", grid, block, SMEM, stream, p);
+    case EPI_GELU: return launch_kernel<ld_gemm8p_mx_kernel<EPI_GELU>>("ld_gemm_mxfp8(8p)", grid, block, SMEM, stream, p);
+    case EPI_GATE: return launch_kernel<ld_gemm8p_mx_kernel<EPI_GATE>>("ld_gemm_mxfp8(8p)", grid, block, SMEM, stream, p);
+    case EPI_GELU_MX: return launch_kernel<ld_gemm8p_mx_kernel<EPI_GELU_MX>>("ld_gemm_mxfp8(8p)", grid, block, SMEM, stream, p);
+    default: return launch_kernel<ld_gemm8p_mx_kernel<EPI_GENERIC>>("ld_gemm_mxfp8(8p)", grid, block, SMEM, stream, p);
+  }
+}
+
 int launch_f8(const GemmParams& p, hipStream_t stream) {
+  // LD_GEMM_MX8P=0: the round-1 two-stage MXFP8 kernel (A/B timing; the fused qkv form exists in the persistent kernel only)
+  static int k_mx8p = LD_KNOB_UNSET;
+  if (p.mx_a && (p.q_out || ld_knob("LD_GEMM_MX8P", 1, &k_mx8p) != 0)) return launch_8p_mx(p, stream);
   constexpr int STAGE = (256 + 256) * 128;
   constexpr int EPIB = 8 * 32 * CW_STRIDE * 4;
   constexpr int SMEM = ((2 * STAGE > EPIB) ? 2 * STAGE : EPIB) + 4096;      // + the MX scale strips of both stages
@@ -2794,6 +3082,33 @@ LD_API int ld_gemm_mxfp8(const void* A8, int64_t lda, const void* scales_a, cons
     p.mx_out = (unsigned char*)out_scales; p.ld_mx_out = ldos;
   }
   return launch_f8(p, (hipStream_t)stream);
+}
+
+/* The fused qkv head split on MXFP8 operands (BASELINE configs[4]): ld_gemm_qkv_heads with A / W as e4m3 codes + block scales. */
+LD_API int ld_gemm_qkv_heads_mxfp8(const void* A8, int64_t lda, const void* scales_a, const void* W8, const void* scales_w,
+                                   const void* bias, int64_t M, int64_t K, void* Q, void* Kh, void* Vt, int64_t B, int64_t Ntok,
+                                   int64_t heads, int64_t Npad, const void* q_w, const void* q_b, const void* k_w, const void* k_b,
+                                   float eps, void* stream) {
+  LD_REQUIRE(A8 && W8 && scales_a && scales_w && bias && Q && Kh && Vt && q_w && q_b && k_w && k_b, "ld_gemm_qkv_heads_mxfp8: null pointer");
+  LD_REQUIRE(M == B * Ntok && B > 0 && heads > 0 && K > 0 && K % 128 == 0, "ld_gemm_qkv_heads_mxfp8: M=%ld must be B*Ntok=%ld, K=%ld a multiple of 128",
+             (long)M, (long)(B * Ntok), (long)K);
+  LD_REQUIRE(Ntok % 8 == 0 && Ntok >= 256 && Npad % 8 == 0 && Npad >= Ntok, "ld_gemm_qkv_heads_mxfp8: Ntok=%ld (multiple of 8, >= 256), Npad=%ld", (long)Ntok, (long)Npad);
+  LD_REQUIRE(lda % 16 == 0 && ((uintptr_t)A8 & 15) == 0 && ((uintptr_t)W8 & 15) == 0 && ((uintptr_t)scales_a & 3) == 0 && ((uintptr_t)scales_w & 3) == 0 &&
+             ((uintptr_t)bias & 15) == 0 && ((uintptr_t)Q & 15) == 0 && ((uintptr_t)Kh & 15) == 0 && ((uintptr_t)Vt & 15) == 0 &&
+             ((uintptr_t)q_w & 15) == 0 && ((uintptr_t)q_b & 15) == 0 && ((uintptr_t)k_w & 15) == 0 && ((uintptr_t)k_b & 15) == 0,
+             "ld_gemm_qkv_heads_mxfp8: alignment (operands 16 B, scales 4 B)");
+  LD_REQUIRE(M * lda < (1LL << 32) && 3 * heads * 64 * K < (1LL << 32) && M < (1LL << 31), "ld_gemm_qkv_heads_mxfp8: operand larger than 4 GiB");
+  GemmParams p{};
+  p.A = (const bf16_t*)A8; p.W = (const bf16_t*)W8; p.out = nullptr;
+  p.M = (int)M; p.N = (int)(3 * heads * 64); p.K = (int)K; p.lda = lda; p.ldo = 0;
+  p.mx_a = (const unsigned char*)scales_a; p.mx_w = (const unsigned char*)scales_w;
+  int rc = fill_epilogue(p, nullptr);
+  if (rc) return rc;
+  p.bias = (const bf16_t*)bias;
+  p.q_out = (bf16_t*)Q; p.k_out = (bf16_t*)Kh; p.vt_out = (bf16_t*)Vt;
+  p.qn_w = (const bf16_t*)q_w; p.qn_b = (const bf16_t*)q_b; p.kn_w = (const bf16_t*)k_w; p.kn_b = (const bf16_t*)k_b;
+  p.heads = (int)heads; p.Ntok = (int)Ntok; p.Npad = (int)Npad; p.qk_eps = eps;
+  return launch_8p_mx(p, (hipStream_t)stream);
 }
 
 #ifdef LD_GEMM_TRACE

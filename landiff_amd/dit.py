@@ -98,7 +98,8 @@ class ControlDiTRunner:
         self.ctrl_out = [e(M, d) for _ in range(c.layers_control)]
         # default (LD_DIT_OVERLAP=0 selects the serial step), see _step_overlapped(): the control branch runs on a second stream, one
         # layer ahead of the main branch, and needs its own copy of every per-layer workspace
-        self.overlap = os.environ.get("LD_DIT_OVERLAP", "1") == "1" and not fp8_gemm
+        # (round 6: also with e4m3 linears -- the quantised-activation buffers are part of the per-chain workspace set)
+        self.overlap = os.environ.get("LD_DIT_OVERLAP", "1") == "1"
         self._sets = []
         for _ in range(2 if self.overlap else 1):
             ws = dict(ln=e(M, d), qkv=e(M, 3 * d),
@@ -107,6 +108,13 @@ class ControlDiTRunner:
                       vt=torch.zeros(B, c.heads, 64, self.Npad, device=device, dtype=BF),
                       attn=e(B, N, d), mlp=e(M, 4 * d), patches=e(c.n_img, c.in_channels * c.patch * c.patch),
                       temb=e(B, d), emb_h=e(B, c.time_embed_dim), emb=e(B, c.time_embed_dim), tvec=e(B, dt=torch.float32))
+            if fp8_gemm:
+                ws["a8"] = torch.empty(M, 4 * d, device=device, dtype=torch.uint8)    # quantised GEMM input (largest K)
+                ws["sa"] = e(M, dt=torch.float32)
+            if fp8_gemm == "mx":
+                ws["a8d"] = torch.empty(M, d, device=device, dtype=torch.uint8)        # MXFP8 activations of width d ...
+                ws["s8d"] = torch.empty(d // 128, M, 4, device=device, dtype=torch.uint8)       # scales, K-tile-major
+                ws["s8m"] = torch.empty(4 * d // 128, M, 4, device=device, dtype=torch.uint8)   # ... and 4d (codes in a8)
             self._sets.append(ws)
         self._use(0)
         self._side = torch.cuda.Stream(device=device) if self.overlap else None
@@ -118,17 +126,11 @@ class ControlDiTRunner:
         self.lin = e(B, c.n_img, c.patch * c.patch * c.out_channels)
         self.txt_main = e(B, c.text_len, d)
         self.txt_ctrl = e(B, c.text_len, d)
-        if fp8_gemm:
-            self.a8 = torch.empty(M, 4 * d, device=device, dtype=torch.uint8)    # quantised GEMM input (largest K)
-            self.sa = e(M, dt=torch.float32)
-        if fp8_gemm == "mx":
-            self.a8d = torch.empty(M, d, device=device, dtype=torch.uint8)        # MXFP8 activations of width d ...
-            self.s8d = torch.empty(d // 128, M, 4, device=device, dtype=torch.uint8)       # scales, K-tile-major
-            self.s8m = torch.empty(4 * d // 128, M, 4, device=device, dtype=torch.uint8)   # ... and 4d (codes in self.a8)
         self.sem = None                         # [T, C, H, W] bf16, set per video
         # qkv Linear + QK-LayerNorm + head split + V transpose in one launch (ld_gemm_qkv_heads) where its shape rules hold;
         # LD_DIT_FUSE_QKV=0 keeps the two-launch form (A/B timing)
-        self.fuse_qkv = (not self.fp8 and self.N % 8 == 0 and self.N >= 256 and c.head_dim == 64
+        # (round 6: also on MXFP8 operands, ld_gemm_qkv_heads_mxfp8; the row-scaled fp8 form keeps the two launches)
+        self.fuse_qkv = (self.fp8 in (False, None, "mx") and self.N % 8 == 0 and self.N >= 256 and c.head_dim == 64
                          and os.environ.get("LD_DIT_FUSE_QKV", "1") != "0")
         self._solo = True
         self.attn_events = None                 # bench.py: list of (start, end, solo) HIP events around every attention launch
@@ -221,18 +223,23 @@ class ControlDiTRunner:
         gate = dict(gate=ada, gate_bstride=ada_bs, rows_per_batch=N, text_len=c.text_len)
         ops.layernorm_mxfp8(h_in, lw["ln1_w"], lw["ln1_b"], self.a8d, self.s8d, c.block_ln_eps, shift_img=0, scale_img=d,
                             shift_txt=6 * d, scale_txt=7 * d, **mod)
-        ops.gemm_mxfp8(self.a8d, self.s8d, lw["qkv_w8"], lw["qkv_s"], out=self.qkv, bias=lw["qkv_b"])
-        ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
+        fl = 2.0 * self.M * d * d                   # (bench.py: HIP events around the e4m3 linears too, flops tagged "mx")
+        if self.fuse_qkv:
+            self._timed((3 * fl, "mx"), ops.gemm_qkv_heads_mxfp8, self.a8d, self.s8d, lw["qkv_w8"], lw["qkv_s"], lw["qkv_b"], self.q, self.k, self.vt,
+                        self.B, N, c.heads, self.Npad, lw["qln"], eps=c.qk_ln_eps)
+        else:
+            self._timed((3 * fl, "mx"), ops.gemm_mxfp8, self.a8d, self.s8d, lw["qkv_w8"], lw["qkv_s"], out=self.qkv, bias=lw["qkv_b"])
+            ops.qkv_split(self.qkv, self.q, self.k, self.vt, self.B, N, c.heads, self.Npad, ln=lw["qln"], eps=c.qk_ln_eps)
         self._attention()
         ops.quantize_mxfp8(self.attn.view(-1, d), self.a8d, self.s8d)
-        ops.gemm_mxfp8(self.a8d, self.s8d, lw["dense_w8"], lw["dense_s"], out=h_out, bias=lw["dense_b"], resid=h_in,
-                       gate_off_img=2 * d, gate_off_txt=8 * d, **gate)
+        self._timed((fl, "mx"), ops.gemm_mxfp8, self.a8d, self.s8d, lw["dense_w8"], lw["dense_s"], out=h_out, bias=lw["dense_b"], resid=h_in,
+                    gate_off_img=2 * d, gate_off_txt=8 * d, **gate)
         ops.layernorm_mxfp8(h_out, lw["ln2_w"], lw["ln2_b"], self.a8d, self.s8d, c.block_ln_eps, shift_img=3 * d, scale_img=4 * d,
                             shift_txt=9 * d, scale_txt=10 * d, **mod)
         a8m = self.a8.view(self.M, 4 * d)
-        ops.gemm_mxfp8(self.a8d, self.s8d, lw["h4_w8"], lw["h4_s"], out=a8m, out_scales=self.s8m, bias=lw["h4_b"], act="gelu_tanh")
-        ops.gemm_mxfp8(a8m, self.s8m, lw["h1_w8"], lw["h1_s"], out=h_out, bias=lw["h1_b"], resid=h_out, gate_off_img=5 * d,
-                       gate_off_txt=11 * d, add2=control_add, **gate)
+        self._timed((4 * fl, "mx"), ops.gemm_mxfp8, self.a8d, self.s8d, lw["h4_w8"], lw["h4_s"], out=a8m, out_scales=self.s8m, bias=lw["h4_b"], act="gelu_tanh")
+        self._timed((4 * fl, "mx"), ops.gemm_mxfp8, a8m, self.s8m, lw["h1_w8"], lw["h1_s"], out=h_out, bias=lw["h1_b"], resid=h_out, gate_off_img=5 * d,
+                    gate_off_txt=11 * d, add2=control_add, **gate)
 
     def _layer(self, br: _Branch, i: int, h_in: torch.Tensor, h_out: torch.Tensor, control_add=None):
         # with the two chains overlapped, only the main layers behind the last control state run with the GPU to themselves

@@ -441,6 +441,19 @@ def gemm_qkv_heads(a, w, bias, q, k, vt, B, N, H, Npad, ln, eps=1e-6):
           "ld_gemm_qkv_heads")
 
 
+def gemm_qkv_heads_mxfp8(a8, sa, w8, sw, bias, q, k, vt, B, N, H, Npad, ln, eps=1e-6):
+    """gemm_qkv_heads on MXFP8 operands: a8 uint8 [B*N, K] + scales sa [K/128, B*N, 4], w8 [3*H*64, K] + sw [K/128, 3*H*64, 4]."""
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(1) == 1 and w8.is_contiguous()
+    M, K = a8.shape
+    assert M == B * N and w8.shape == (3 * H * 64, K) and tuple(sa.shape) == (K // 128, M, 4) and tuple(sw.shape) == (K // 128, 3 * H * 64, 4)
+    assert sa.is_contiguous() and sw.is_contiguous() and sa.dtype == torch.uint8 and sw.dtype == torch.uint8
+    assert q.shape == (B, H, Npad, 64) and k.shape == q.shape and vt.shape == (B, H, 64, Npad)
+    assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    check(_lib.load().ld_gemm_qkv_heads_mxfp8(_ptr(a8), a8.stride(0), _ptr(sa), _ptr(w8), _ptr(sw), _ptr(bias), M, K, _ptr(q), _ptr(k), _ptr(vt),
+                                              B, N, H, Npad, _ptr(ln[0]), _ptr(ln[1]), _ptr(ln[2]), _ptr(ln[3]), float(eps), _stream()),
+          "ld_gemm_qkv_heads_mxfp8")
+
+
 def qkv_split(qkv, q, k, vt, B, N, H, Npad, *, ln=None, rope=None, eps=1e-6):
     """ln = (q_w, q_b, k_w, k_b) for the DiT QK-LayerNorm, or rope = (cos, sin) [N,32] fp32 for TiTok."""
     mode = 0 if ln is not None else 1

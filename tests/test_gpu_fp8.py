@@ -124,9 +124,15 @@ def test_quantize_mxfp8(cuda, M, K):
     assert rel < 0.05, rel
 
 
-@pytest.mark.parametrize("M,N,K,form", [(256, 256, 128, "plain"), (300, 200, 256, "bias"), (1000, 1920, 1920, "gelu"), (777, 1920, 7680, "resid")])
-def test_gemm_mxfp8_exact_operands(cuda, M, N, K, form):
+@pytest.mark.parametrize("loop", ["8p", "2stage"])
+@pytest.mark.parametrize("M,N,K,form", [(256, 256, 128, "plain"), (300, 200, 256, "bias"), (1000, 1920, 1920, "gelu"), (777, 1920, 7680, "resid"),
+                                        (70003, 1000, 384, "bias")])
+def test_gemm_mxfp8_exact_operands(cuda, monkeypatch, M, N, K, form, loop):
+    """Both MXFP8 main loops -- the persistent two-phase loop on v_mfma_scale_f32_16x16x128_f8f6f4 (round 6, default) and the
+    round-1 two-stage loop on 32x32x64 (LD_GEMM_MX8P=0, re-read per call under LD_TUNING=1) -- against the dequantised operands
+    multiplied in fp64: wildly different block scales along K, ragged M / N, one / three / odd numbers of K-tiles, more tiles than CUs."""
     from landiff_amd import ops
+    monkeypatch.setenv("LD_GEMM_MX8P", "1" if loop == "8p" else "0")
     g = torch.Generator().manual_seed(M * 5 + N)
     a = (torch.randn(M, K, generator=g) * torch.logspace(-2, 1, K // 32).repeat_interleave(32)[None, :]).to(BF)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
@@ -149,6 +155,41 @@ def test_gemm_mxfp8_exact_operands(cuda, M, N, K, form):
     want = post(ref.float())
     err = (out.float().cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-6)
     assert err < 1e-2, err
+
+
+@pytest.mark.parametrize("B,N,H,K", [(2, 304, 3, 256), (1, 1000, 30, 1920), (2, 17776, 30, 1920)])
+def test_gemm_qkv_heads_mxfp8_fused_split(cuda, B, N, H, K):
+    """ld_gemm_qkv_heads_mxfp8 against the two launches it replaces on the same MXFP8 operands (ld_gemm_mxfp8 + ld_qkv_split): V is the
+    same bf16 values moved (exact), q / k the same fp32 LayerNorm on the same bf16 inputs (one ulp where a multiply-add contracts
+    differently), padding rows untouched; and against a torch restatement on the dequantised operands."""
+    from landiff_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    Npad = (N + 127) // 128 * 128
+    a = torch.randn(B * N, K, generator=g).to(cuda, BF)
+    w = (torch.randn(3 * H * 64, K, generator=g) * 0.08).to(cuda, BF)
+    bias = torch.randn(3 * H * 64, generator=g).to(cuda, BF)
+    ln = tuple((torch.randn(64, generator=g) * s_ + o).to(cuda, BF) for s_, o in ((0.2, 1.0), (0.2, 0.0), (0.2, 1.0), (0.2, 0.0)))
+    a8, sa = ops.quantize_mxfp8(a); w8, sw = ops.quantize_mxfp8(w)
+    mk = lambda: (torch.zeros(B, H, Npad, 64, device=cuda, dtype=BF), torch.zeros(B, H, Npad, 64, device=cuda, dtype=BF),
+                  torch.zeros(B, H, 64, Npad, device=cuda, dtype=BF))
+    q1, k1, v1 = mk()
+    ops.gemm_qkv_heads_mxfp8(a8, sa, w8, sw, bias, q1, k1, v1, B, N, H, Npad, ln, eps=1e-6)
+    q2, k2, v2 = mk()
+    qkv = ops.gemm_mxfp8(a8, sa, w8, sw, bias=bias)
+    ops.qkv_split(qkv, q2, k2, v2, B, N, H, Npad, ln=ln, eps=1e-6)
+    assert torch.equal(v1, v2)
+    for x1, x2 in ((q1, q2), (k1, k2)):
+        d = (x1.float() - x2.float()).abs()
+        assert (d <= 2.0 ** -7 * x2.float().abs() + 1e-6).all(), d.max().item()
+        assert (x1 != x2).float().mean().item() < 1e-3
+    assert float(q1[:, :, N:].abs().max()) == 0.0 and float(v1[:, :, :, N:].abs().max()) == 0.0
+    if N <= 1000:
+        y = (_mx_deq(a8.cpu(), _row_major(sa.cpu())) @ _mx_deq(w8.cpu(), _row_major(sw.cpu())).t() + bias.float().cpu()).to(BF).float().view(B, N, 3, H, 64)
+        lnf = lambda t, wv, bv: torch.nn.functional.layer_norm(t, (64,), wv.float().cpu(), bv.float().cpu(), 1e-6)
+        rel = lambda x, r: ((x.float().cpu() - r).abs().max() / r.abs().max()).item()
+        assert rel(q1[:, :, :N], lnf(y[:, :, 0], ln[0], ln[1]).permute(0, 2, 1, 3)) < 1.5e-2
+        assert rel(k1[:, :, :N], lnf(y[:, :, 1], ln[2], ln[3]).permute(0, 2, 1, 3)) < 1.5e-2
+        assert rel(v1[:, :, :, :N], y[:, :, 2].permute(0, 2, 3, 1)) < 1e-2
 
 
 def test_mxfp8_chain_vs_bf16_gemm(cuda):
