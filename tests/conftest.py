@@ -95,9 +95,14 @@ RUN_LAST = ("test_infer_video_entry_point_config0",)
 
 
 def pytest_collection_modifyitems(session, config, items):
-    last = [it for it in items if it.nodeid.split("::")[-1].split("[")[0] in RUN_LAST]
-    if last:
-        items[:] = [it for it in items if it not in last] + last
+    """Order: everything else, then the tests that JOIN a background oracle job (by then the jobs have had the whole session to
+    finish: no waiting), then the CPU-heavy tests that need the whole cpuset."""
+    from oracle_jobs import CONSUMERS
+    name = lambda it: it.nodeid.split("::")[-1].split("[")[0]
+    join = [it for it in items if name(it) in CONSUMERS]
+    last = [it for it in items if name(it) in RUN_LAST]
+    if join or last:
+        items[:] = [it for it in items if it not in join and it not in last] + join + last
 
 
 def pytest_collection_finish(session):
@@ -112,7 +117,7 @@ def pytest_collection_finish(session):
     if want and not session.config.option.collectonly:
         _JOBS = OracleJobs()
         # core plan: pytest keeps the lower half of its cpuset, the jobs split the upper half by weight (the VAE decode is the long one)
-        weight = {"vae_two_chunks": 4, "llm_two_blocks_fp32": 2, "llm_two_blocks_bf16": 2, "dit_3p3_eps": 2}
+        weight = {"vae_two_chunks": 4, "llm_two_blocks_fp32": 2, "llm_two_blocks_bf16": 2, "dit_3p3_eps": 2, "dit_layer": 1, "vae_level0": 2}
         cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
         plan = {}
         if len(cpus) >= 4 * len(want):

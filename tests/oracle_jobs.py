@@ -121,17 +121,68 @@ def job_dit_3p3_eps():
             torch.cat([x, x]), torch.full((2,), float(timestep)), torch.cat([torch.zeros_like(ctx), ctx]), sem.float()).float()
 
 
+# ---- test_gpu_fullsize.py::test_dit_layer_full_shape_vs_oracle ----
+def dit_layer_inputs():
+    from landiff_amd.config import PipelineConfig
+    from landiff_amd.weights import dit_spec, init_state
+    d1 = dataclasses.replace(PipelineConfig.full().dit, layers_main=1, layers_control=1)
+    sd_main = init_state(dit_spec(d1, False), 1)
+    sd_ctrl = init_state(dit_spec(d1, True), 2)
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn(2, d1.seq_len, d1.hidden, generator=g).to(torch.bfloat16)
+    emb = torch.randn(2, d1.time_embed_dim, generator=g).to(torch.bfloat16)
+    return d1, sd_main, sd_ctrl, h, emb
+
+
+def job_dit_layer():
+    """fp32 oracle output of one main AdaLN layer at the BASELINE shape (the call bench.py's cpu_baseline times)."""
+    from oracle.dit import DiTOracle
+    d1, sd_main, _, h, emb = dit_layer_inputs()
+    _threads(32)
+    with torch.no_grad():
+        return DiTOracle(sd_main, d1, False, torch.float32).layer(0, h.float(), emb.float())
+
+
+# ---- test_gpu_fullsize.py::test_vae_level0_resblock_full_resolution_vs_oracle ----
+def vae_level0_inputs():
+    from landiff_amd.config import VAEConfig
+    from landiff_amd.weights import _res3d, init_state
+    cfg = VAEConfig()
+    C, T, H, W = 128, 4, 480, 720
+    p = "decoder.up.0.block.1."
+    sd = init_state(_res3d(p, C, C, cfg.z_channels), 31)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, C, T, H, W, generator=g).to(torch.bfloat16)
+    zq = torch.randn(1, cfg.z_channels, 1, 60, 90, generator=g).to(torch.bfloat16)
+    return cfg, sd, p, C, T, H, W, x, zq
+
+
+def job_vae_level0():
+    """(fp32, bf16) oracle outputs of one level-0 resblock at 480 x 720."""
+    from oracle.vae import VAEDecoderOracle
+    cfg, sd, p, C, T, H, W, x, zq = vae_level0_inputs()
+    _threads(32)
+    with torch.no_grad():
+        ref32 = VAEDecoderOracle(sd, cfg, torch.float32).resblock(x.float(), zq.float(), p, C, C, True)[0]
+        ref16 = VAEDecoderOracle(sd, cfg, torch.bfloat16).resblock(x, zq, p, C, C, True)[0].float()
+    return ref32, ref16
+
+
 JOBS = {
     "vae_two_chunks": job_vae_two_chunks,
     "llm_two_blocks_fp32": job_llm_two_blocks_fp32,
     "llm_two_blocks_bf16": job_llm_two_blocks_bf16,
     "dit_3p3_eps": job_dit_3p3_eps,
+    "dit_layer": job_dit_layer,
+    "vae_level0": job_vae_level0,
 }
 # which jobs a test (matched by the end of its node id) joins: conftest.py starts exactly these after collection
 CONSUMERS = {
     "test_vae_full_resolution_two_chunks_vs_oracle": ["vae_two_chunks"],
     "test_llm_two_blocks_full_width_decode_at_real_context_lengths_vs_oracle": ["llm_two_blocks_fp32", "llm_two_blocks_bf16"],
     "test_dit_multi_layer_step_full_shape_vs_oracle": ["dit_3p3_eps"],
+    "test_dit_layer_full_shape_vs_oracle": ["dit_layer"],
+    "test_vae_level0_resblock_full_resolution_vs_oracle": ["vae_level0"],
 }
 
 

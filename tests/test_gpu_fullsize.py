@@ -119,24 +119,14 @@ def test_llm_full_size_decode_properties(cuda):
     assert not torch.equal(t1, t4)
 
 
-def test_dit_layer_full_shape_vs_oracle(cuda):
+def test_dit_layer_full_shape_vs_oracle(cuda, oracle_bg):
     """One AdaLN layer of the main DiT at the BASELINE shape (B=2 CFG pair, 17 776 tokens, hidden 1920, 30 heads) through
     the HIP path -- pipelined attention kernel, specialised GEMM epilogues, M-split launches -- against the fp32 oracle on
-    the host cores (the same call bench.py's cpu_baseline times, ~10 s)."""
-    import dataclasses
-    from landiff_amd.config import PipelineConfig
+    the host cores (the same call bench.py's cpu_baseline times, ~10 s; a background job of the session: tests/oracle_jobs.py)."""
     from landiff_amd.dit import ControlDiTRunner
-    from landiff_amd.weights import dit_spec, init_state
-    from oracle.dit import DiTOracle
-    d1 = dataclasses.replace(PipelineConfig.full().dit, layers_main=1, layers_control=1)
-    sd_main = init_state(dit_spec(d1, False), 1)
-    sd_ctrl = init_state(dit_spec(d1, True), 2)
-    g = torch.Generator().manual_seed(5)
-    h = torch.randn(2, d1.seq_len, d1.hidden, generator=g).to(torch.bfloat16)
-    emb = torch.randn(2, d1.time_embed_dim, generator=g).to(torch.bfloat16)
-    torch.set_num_threads(min(64, torch.get_num_threads() * 8))
-    with torch.no_grad():
-        ref = DiTOracle(sd_main, d1, False, torch.float32).layer(0, h.float(), emb.float())
+    from oracle_jobs import dit_layer_inputs
+    d1, sd_main, sd_ctrl, h, emb = dit_layer_inputs()
+    ref, _ = oracle_bg.result("dit_layer")
     run = ControlDiTRunner(sd_main, sd_ctrl, d1, cuda)
     run.emb.copy_(emb.to(cuda))
     run._modulations(run.main)
@@ -345,22 +335,14 @@ def test_titok_decoder_layer_full_size_vs_oracle(cuda):
     assert torch.equal(got2[0], got[0]) and not torch.equal(got2[1], got[1])
 
 
-def test_vae_level0_resblock_full_resolution_vs_oracle(cuda):
+def test_vae_level0_resblock_full_resolution_vs_oracle(cuda, oracle_bg):
     """One level-0 resblock of the 3D-VAE decoder at 480 x 720 (128 channels, 4 frames = half a chunk): SpatialNorm3D with the
     latent-resolution conv_y / conv_b gather + swish, causal 3x3x3 conv with the replicated-first-frame halo, twice, + residual
     -- HIP path vs the fp32 oracle (the unit BASELINE.md section 3 names for the CPU baseline), 2x-floor rule."""
-    from landiff_amd.config import VAEConfig
     from landiff_amd.vae import VAEDecoder, ZQ_PAD
-    from landiff_amd.weights import _res3d, init_state
-    from oracle.vae import VAEDecoderOracle
-    cfg = VAEConfig()
-    C, T, H, W = 128, 4, 480, 720
+    from oracle_jobs import vae_level0_inputs
+    cfg, sd, p, C, T, H, W, x, zq = vae_level0_inputs()
     Tz, hz, wz = 1, 60, 90
-    p = "decoder.up.0.block.1."
-    sd = init_state(_res3d(p, C, C, cfg.z_channels), 31)
-    g = torch.Generator().manual_seed(7)
-    x = torch.randn(1, C, T, H, W, generator=g).to(torch.bfloat16)
-    zq = torch.randn(1, cfg.z_channels, Tz, hz, wz, generator=g).to(torch.bfloat16)
     dec = VAEDecoder(sd, cfg, cuda)
     x_cl = x[0].permute(1, 2, 3, 0).reshape(T * H * W, C).contiguous().to(cuda)
     z_cl = torch.zeros(Tz * hz * wz, ZQ_PAD, device=cuda, dtype=torch.bfloat16)
@@ -370,10 +352,7 @@ def test_vae_level0_resblock_full_resolution_vs_oracle(cuda):
     assert dec.fuse_gn_stats and part is not None
     got = out.view(T, H, W, C).permute(3, 0, 1, 2).float().cpu()
     del dec, out, x_cl, part
-    torch.set_num_threads(min(64, max(torch.get_num_threads(), torch.get_num_threads() * 8)))
-    with torch.no_grad():
-        ref32 = VAEDecoderOracle(sd, cfg, torch.float32).resblock(x.float(), zq.float(), p, C, C, True)[0]
-        ref16 = VAEDecoderOracle(sd, cfg, torch.bfloat16).resblock(x, zq, p, C, C, True)[0].float()
+    (ref32, ref16), _ = oracle_bg.result("vae_level0")
     assert got.shape == ref32.shape == (C, T, H, W)
     floor, err = _rel(ref16, ref32), _rel(got, ref32)
     mean_err = (got - ref32).abs().mean().item() / ref32.abs().mean().item()
