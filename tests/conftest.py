@@ -91,7 +91,7 @@ _JOBS = None
 
 # CPU-heavy tests whose oracle legs depend on device outputs (they cannot be started ahead): run them LAST, when the background jobs
 # have been joined and pytest has the whole cpuset again
-RUN_LAST = ("test_infer_video_entry_point_config0",)
+RUN_LAST = ("test_llm_full_size_prefill_and_decode_vs_oracle", "test_infer_video_entry_point_config0")
 
 
 def pytest_collection_modifyitems(session, config, items):
