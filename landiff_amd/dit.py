@@ -182,8 +182,9 @@ class ControlDiTRunner:
             ops.gemm(self.patches, br.patch_w, out=hv[b, c.text_len:], bias=br.patch_b, add2=br.pos[c.text_len:])
             hv[b, :c.text_len].copy_(txt[b])
 
-    def _timed(self, flops: float, fn, *a, **kw):
-        """fn(*a, **kw), bracketed by HIP events on the current stream when bench.py asked for GEMM timings."""
+    def _timed(self, flops, fn, *a, **kw):
+        """fn(*a, **kw), bracketed by HIP events on the current stream when bench.py asked for GEMM timings.  flops: the launch's
+        2 M N K, or (2 M N K, "mx") for an e4m3 linear (bench.py prices those against the MX-fp8 peak)."""
         if self.gemm_events is None:
             return fn(*a, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
