@@ -26,8 +26,9 @@ extern "C" {
  * argument, ld_gemm_qkv_heads / ld_llm_sample_advance / ld_groupnorm_stats_blocks / ld_attn_last_kernel were added).  A caller
  * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does).
  * 6: ld_reset and ld_attn_queue_poke were added.  7: ld_conv_cl_bf16_gn, ld_conv_gn_partials_size and
- * ld_groupnorm_stats_from_conv were added.  8: ld_gemm_qkv_heads_mxfp8 was added. */
-#define LD_ABI_VERSION 8
+ * ld_groupnorm_stats_from_conv were added.  8: ld_gemm_qkv_heads_mxfp8 was added.
+ * 9: ld_attn_fwd_bf16_exact was added. */
+#define LD_ABI_VERSION 9
 
 int ld_version(void);
 const char* ld_last_error(void);
@@ -184,6 +185,18 @@ int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
                      int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
                      const int32_t* fid_q, const int32_t* fid_k,
                      const int32_t* kt_min, const int32_t* kt_max, void* stream);
+
+/* The same operation with an exact safe softmax for ANY logit range at a fixed cost (~1.55 x ld_attn_fwd_bf16's launch at the DiT
+ * shape): for checkpoints whose q.k * softmax_scale row maxima leave the window of the default launch's max-free fast pass (beyond ~76
+ * in natural-log units, i.e. denominators beyond 2^110; profiles/r06_attn_logit_sweep.txt), where the default launch stays correct
+ * but re-runs every affected 256-row block (up to 2.6 x).  Unmasked problems of >= 6 key tiles: two passes over the keys (row maxima
+ * from QK^T only, then the pipelined loop with -max as the score accumulators' initial value; ld_attn_q64_exact.hip); every other
+ * shape: the plain online-softmax kernel ld_attn_fwd_bf16 itself uses there.  No data-dependent branch; run to run identical. */
+int ld_attn_fwd_bf16_exact(const void* Q, const void* K, const void* Vt, void* O,
+                           int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
+                           int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
+                           const int32_t* fid_q, const int32_t* fid_k,
+                           const int32_t* kt_min, const int32_t* kt_max, void* stream);
 
 /* Forgets the stream -> counter-set assignments of the current device and zeroes its sets (asynchronously on `stream`).
  * Only for a process that keeps creating streams, or after a device error: the caller guarantees that no ld_attn_fwd_bf16

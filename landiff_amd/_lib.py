@@ -44,7 +44,7 @@ class LlmLayer(Structure):
 
 
 _lib = None
-ABI_VERSION = 8          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
+ABI_VERSION = 9          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
 
 I64 = c_int64
 I32 = c_int32
@@ -63,6 +63,7 @@ SIGNATURES: dict[str, list] = {
     "ld_calib_mfma_bf16": [P, I64, P, I64, I64, POINTER(c_double), P],
     "ld_calib_stream_read": [P, I64, P, P],
     "ld_attn_fwd_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_float, P, P, P, P, P],
+    "ld_attn_fwd_bf16_exact": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_float, P, P, P, P, P],
     "ld_attn_last_kernel": [],
     "ld_reset": [P],
     "ld_attn_queue_poke": [I32, c_uint32, P],

@@ -7,7 +7,7 @@
 set -e
 cd "$(dirname "$0")"
 VARIANT_ONLY="ld_attn_pipe.hip ld_attn_q128.hip ld_llm_fused.hip"
-HDRS="ld_common.h ld_attn.h ld_llm_dev.h ../../include/landiff_hip.h build.sh"      # (build.sh: a change of flags rebuilds everything)
+HDRS="ld_common.h ld_attn.h ld_attn_q64_body.h ld_llm_dev.h ../../include/landiff_hip.h build.sh"      # (build.sh: a change of flags rebuilds everything)
 
 build_lib() {   # $1 = object dir, $2 = output, $3 = extra flags, $4.. = sources
   local objdir=$1 out=$2 flags=$3; shift 3
@@ -25,7 +25,7 @@ build_lib() {   # $1 = object dir, $2 = output, $3 = extra flags, $4.. = sources
       # round 5) it emits v_pk_*_f32 whose LOW lane reads the HIGH register of an operand pair (op_sel) for RoPE-like expressions, and
       # that operand form reads 0.0 in lanes 48-63 when MFMA waves of another kernel share the SIMD (tools/probe/pk_f32_coresidency.hip).
       # tools/audit_pk_f32.py checks the BUILT library for the form (a CPU test), whatever the flags of a file are.
-      case $s in ld_attn_pipe.hip|ld_attn_p16.hip|ld_attn_q64.hip|ld_attn_q128.hip|ld_norm.hip) extra="-fno-slp-vectorize";; esac
+      case $s in ld_attn_pipe.hip|ld_attn_p16.hip|ld_attn_q64.hip|ld_attn_q64_exact.hip|ld_attn_q128.hip|ld_norm.hip) extra="-fno-slp-vectorize";; esac
       # the forms of the decode step (one launch per operation / chained / one persistent launch) must produce the same bits: no
       # implicit mul+add fusion, whose outcome depends on the code around an expression (explicit fmaf / dot2 are unaffected).
       # -fno-slp-vectorize (round 5): the vectoriser turns e.g. RoPE's `a*c - b*s` / `a*s + b*c` into v_pk_mul_f32 / v_pk_add_f32 with

@@ -355,11 +355,13 @@ static thread_local const char* g_attn_last_kernel = "";
 void ld_attn_set_last_kernel(const char* name) { g_attn_last_kernel = name; }
 LD_API const char* ld_attn_last_kernel(void) { return g_attn_last_kernel; }
 
-LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
-                            int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
-                            int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
-                            const int32_t* fid_q, const int32_t* fid_k,
-                            const int32_t* kt_min, const int32_t* kt_max, void* stream) {
+int ld_attn_q64_exact_launch(const AttnParams& p, hipStream_t st);   // ld_attn_q64_exact.hip
+
+static int attn_fwd_impl(const void* Q, const void* K, const void* Vt, void* O,
+                         int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
+                         int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
+                         const int32_t* fid_q, const int32_t* fid_k,
+                         const int32_t* kt_min, const int32_t* kt_max, void* stream, bool exact) {
   LD_REQUIRE(Q && K && Vt && O, "ld_attn_fwd_bf16: null pointer");
   LD_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "ld_attn_fwd_bf16: empty problem");
   LD_REQUIRE(Npad % QB == 0 && Npad >= Nq && Npad >= Nk, "ld_attn_fwd_bf16: Npad=%ld must be a multiple of %d and >= Nq,Nk", (long)Npad, QB);
@@ -393,13 +395,16 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
   // Like every knob it is read once, or per call under LD_TUNING=1 (ld_common.h) so that one process can time both tiles.
   static int k_q128 = LD_KNOB_UNSET;
   const int q128 = ld_knob("LD_ATTN_Q128", 0, &k_q128);
-  if (var == 0 && !fid_k && nkt >= 6 && (q128 == 2 || (q128 == 1 && B * H * ((Npad + 511) / 512) >= 512)))
+  if (var == 0 && !exact && !fid_k && nkt >= 6 && (q128 == 2 || (q128 == 1 && B * H * ((Npad + 511) / 512) >= 512)))
     return ld_attn_q128_launch(p, st);
 #endif
-  if (var == 0 && !fid_k && nkt >= 6 && q64) return ld_attn_q64_launch(p, st);
-  if (var == 0 && !fid_k && nkt >= 6) return ld_attn_p16_launch(p, st);                  // any tile count
+  // exact form: the two-pass kernel where the pipelined tile applies; every other shape takes the plain kernel below, whose online
+  // softmax is exact for any logit range already
+  if (exact && !fid_k && nkt >= 6) return ld_attn_q64_exact_launch(p, st);
+  if (var == 0 && !fid_k && nkt >= 6 && q64 && !exact) return ld_attn_q64_launch(p, st);
+  if (var == 0 && !fid_k && nkt >= 6 && !exact) return ld_attn_p16_launch(p, st);        // any tile count
 #ifdef LD_VARIANTS
-  if (var == 8 && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) return ld_attn_pipe2_launch(p, st);   // (the round-1 kernel: tile counts 4 m + 2)
+  if (var == 8 && !exact && !fid_k && nkt >= 6 && (nkt - 2) % 4 == 0) return ld_attn_pipe2_launch(p, st);   // (the round-1 kernel: tile counts 4 m + 2)
 #endif
   if (var == 1) {
     g_attn_last_kernel = "ld_attn_kernel<1,true,false,true,2>";
@@ -412,4 +417,20 @@ LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* 
     hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 3>), grid, block, s1, st, p);
   }
   return ld_check_launch("ld_attn_fwd_bf16");
+}
+
+LD_API int ld_attn_fwd_bf16(const void* Q, const void* K, const void* Vt, void* O,
+                            int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
+                            int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
+                            const int32_t* fid_q, const int32_t* fid_k,
+                            const int32_t* kt_min, const int32_t* kt_max, void* stream) {
+  return attn_fwd_impl(Q, K, Vt, O, B, H, Nq, Nk, Npad, o_batch_stride, o_row_stride, softmax_scale, fid_q, fid_k, kt_min, kt_max, stream, false);
+}
+
+LD_API int ld_attn_fwd_bf16_exact(const void* Q, const void* K, const void* Vt, void* O,
+                                  int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
+                                  int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
+                                  const int32_t* fid_q, const int32_t* fid_k,
+                                  const int32_t* kt_min, const int32_t* kt_max, void* stream) {
+  return attn_fwd_impl(Q, K, Vt, O, B, H, Nq, Nk, Npad, o_batch_stride, o_row_stride, softmax_scale, fid_q, fid_k, kt_min, kt_max, stream, true);
 }

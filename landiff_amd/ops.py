@@ -185,10 +185,11 @@ def conv_cl(x_padded: torch.Tensor, w: torch.Tensor, T: int, H: int, W: int,
 
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, Nq: int, Nk: int,
-             scale: float, fid_q=None, fid_k=None, kt_min=None, kt_max=None, q_row0: int = 0) -> torch.Tensor:
+             scale: float, fid_q=None, fid_k=None, kt_min=None, kt_max=None, q_row0: int = 0, exact: bool = False) -> torch.Tensor:
     """q,k [B,H,Npad,64]; vt [B,H,64,Npad]; out [B,N,H*64] (bf16).  Optional frame mask arrays (int32).
     q_row0: the Nq query rows start at row q_row0 of q / fid_q / out (pointer offsets only; Npad must cover
-    q_row0 + Nq rounded up to 128)."""
+    q_row0 + Nq rounded up to 128).  exact: ld_attn_fwd_bf16_exact -- the two-pass safe softmax at a fixed ~1.55 x, for logit
+    ranges beyond the window of the default launch's fast pass."""
     _bf16(q, "q"); _bf16(k, "k"); _bf16(vt, "vt"); _bf16(out, "out")
     B, H, Npad, D = q.shape
     assert D == 64 and k.shape == q.shape and tuple(vt.shape) == (B, H, 64, Npad)
@@ -201,10 +202,10 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tens
         qp = ctypes.c_void_p(qp.value + q_row0 * 64 * 2)
         op = ctypes.c_void_p(op.value + q_row0 * out.stride(1) * 2)
         fqp = ctypes.c_void_p(fqp.value + q_row0 * 4) if fqp is not None else None
-    check(lib.ld_attn_fwd_bf16(qp, _ptr(k), _ptr(vt), op, B, H, Nq, Nk, Npad,
-                               out.stride(0), out.stride(1), float(scale),
-                               fqp, _ptr(fid_k), _ptr(kt_min), _ptr(kt_max), _stream()),
-          "ld_attn_fwd_bf16")
+    fn = lib.ld_attn_fwd_bf16_exact if exact else lib.ld_attn_fwd_bf16
+    check(fn(qp, _ptr(k), _ptr(vt), op, B, H, Nq, Nk, Npad, out.stride(0), out.stride(1), float(scale),
+             fqp, _ptr(fid_k), _ptr(kt_min), _ptr(kt_max), _stream()),
+          "ld_attn_fwd_bf16_exact" if exact else "ld_attn_fwd_bf16")
     return out
 
 

@@ -271,3 +271,40 @@ def test_attn_fallback_at_the_dit_shape_with_sink_keys(cuda, monkeypatch, T, fra
     ops.attn_fwd(q, k, vt, ref, N, N, 0.125)
     assert _last_kernel() == "ld_attn_q64_kernel"
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("T,frac,sink_key", [(None, 0.0, 0), (90, 0.1, 0), (120, 1.0, 0), (90, 0.3, 17775), (-70, 0.2, 0)])
+def test_attn_exact_form_any_logit_range(cuda, T, frac, sink_key):
+    """ld_attn_fwd_bf16_exact at the DiT shape: row maxima first, then the pipelined loop with -max as the score accumulators' initial
+    value -- benign data, sinks far outside the fast pass's window (at the first and at the last key), the underflow side.  Against
+    torch fp32 on three heads, run to run identical; on benign data within bf16 rounding of the default launch (the same bf16 scores,
+    2^(s - max) instead of 2^s); on the out-of-window problems within bf16 rounding of the default launch's in-kernel fallback."""
+    from landiff_amd import ops
+    if T is None:
+        B, H, N = 2, 30, 17776
+        q, k, vt = _qkv(cuda, B, H, N, seed=77)
+    else:
+        q, k, vt, _, B, H, N = _sink_problem(cuda, T, frac, sink_key)
+    out = torch.full((B, N, H * 64), float("nan"), device=cuda, dtype=torch.bfloat16)
+    ops.attn_fwd(q, k, vt, out, N, N, 0.125, exact=True)
+    assert _last_kernel() == "ld_attn_q64_exact_kernel"
+    assert _err_vs_fp32(q, k, vt, out, N, [(0, 0), (1, 17), (1, 29)]) < 3e-2
+    out2 = torch.full_like(out, float("nan"))
+    ops.attn_fwd(q, k, vt, out2, N, N, 0.125, exact=True)
+    assert torch.equal(out, out2)
+    ref = torch.full_like(out, float("nan"))
+    ops.attn_fwd(q, k, vt, ref, N, N, 0.125)
+    d = (out.float() - ref.float()).abs().max().item() / ref.float().abs().max().item()
+    assert d < 2e-2, d
+
+
+def test_attn_exact_form_small_and_masked_shapes_take_the_plain_kernel(cuda):
+    """Shapes outside the pipelined tile (fewer than 6 key tiles; frame masks) run the plain online-softmax kernel in both entry
+    points: the same bits."""
+    from landiff_amd import ops
+    B, H, N = 1, 2, 300
+    q, k, vt = _qkv(cuda, B, H, N, seed=3)
+    a = torch.zeros(B, N, H * 64, device=cuda, dtype=torch.bfloat16); b = torch.zeros_like(a)
+    ops.attn_fwd(q, k, vt, a, N, N, 0.125)
+    ops.attn_fwd(q, k, vt, b, N, N, 0.125, exact=True)
+    assert torch.equal(a, b) and _last_kernel().startswith("ld_attn_kernel")

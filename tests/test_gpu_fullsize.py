@@ -142,6 +142,32 @@ def test_dit_layer_full_shape_vs_oracle(cuda, oracle_bg):
     assert err.mean().item() / ref.abs().mean().item() < 1e-2, (err.mean().item(), ref.abs().mean().item())
 
 
+def test_dit_layer_exact_attention_flag_at_full_shape(cuda, monkeypatch):
+    """ControlDiTRunner(attn_exact=True) / LD_DIT_ATTN_EXACT=1 routes the layer's attention through ld_attn_fwd_bf16_exact (two-pass
+    safe softmax): on data inside the fast pass's window the layer output agrees with the default runner's to bf16 rounding."""
+    from landiff_amd import _lib
+    from landiff_amd.dit import ControlDiTRunner
+    from oracle_jobs import dit_layer_inputs
+    d1, sd_main, sd_ctrl, h, emb = dit_layer_inputs()
+    outs = []
+    for flag in (False, True):
+        run = ControlDiTRunner(sd_main, sd_ctrl, d1, cuda, attn_exact=flag)
+        run.emb.copy_(emb.to(cuda))
+        run._modulations(run.main)
+        h_dev = h.to(cuda).reshape(-1, d1.hidden).contiguous()
+        out = torch.empty_like(h_dev)
+        run._layer(run.main, 0, h_dev, out)
+        torch.cuda.synchronize()
+        assert (_lib.load().ld_attn_last_kernel() or b"").decode() == ("ld_attn_q64_exact_kernel" if flag else "ld_attn_q64_dyn_kernel")
+        outs.append(out.float().cpu())
+        del run
+    assert torch.isfinite(outs[1]).all()
+    d = (outs[0] - outs[1]).abs().max().item() / outs[0].abs().max().item()
+    assert d < 2e-2, d
+    monkeypatch.setenv("LD_DIT_ATTN_EXACT", "1")
+    assert ControlDiTRunner(sd_main, sd_ctrl, d1, cuda).attn_exact is True
+
+
 def test_dit_multi_layer_step_full_shape_vs_oracle(cuda, oracle_bg):
     """A whole denoiser evaluation at the BASELINE shape with the depth cut to 3 control + 3 main layers (B=2 CFG pair, 13 x 30 x 45
     image tokens + 226 text tokens, hidden 1920): patch / text embedding with the semantic condition added on the control side,

@@ -76,14 +76,14 @@ def error_vs_fp32(q, k, heads=((0, 0), (1, 17))):
     return worst
 
 
-def time_launch(q, k):
+def time_launch(q, k, exact=False):
     for _ in range(2):
-        ops.attn_fwd(q, k, vt, out, N, N, 0.125)
+        ops.attn_fwd(q, k, vt, out, N, N, 0.125, exact=exact)
     torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); ops.attn_fwd(q, k, vt, out, N, N, 0.125); e1.record()
+        e0.record(); ops.attn_fwd(q, k, vt, out, N, N, 0.125, exact=exact); e1.record()
         torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     ts.sort()
     return ts[len(ts) // 2]
@@ -97,10 +97,14 @@ os.environ["LD_ATTN_SAFE"] = "1"
 safe = time_launch(q, k)
 os.environ["LD_ATTN_SAFE"] = "0"
 print(f"benign, running-max pass forced            : {safe:.3f} ms = {safe / base:.2f} x the fast pass   error vs fp32 {error_vs_fp32(q, k):.4f}")
+ex = time_launch(q, k, exact=True)
+print(f"benign, ld_attn_fwd_bf16_exact (two passes): {ex:.3f} ms = {ex / base:.2f} x the fast pass   error vs fp32 {error_vs_fp32(q, k):.4f}")
 for T, frac in [(10, 1.0), (30, 1.0), (50, 1.0), (70, 1.0), (76, 1.0), (80, 1.0), (90, 1.0), (110, 1.0), (90, 0.01), (90, 0.10), (90, 0.5), (-70, 1.0)]:
     q, k, sel = make(T, frac)
     ms = time_launch(q, k)
     fb, top = left_window(q, k)
     err = error_vs_fp32(q, k)
+    ex = time_launch(q, k, exact=True)
+    err_ex = error_vs_fp32(q, k)
     print(f"sink logit {T:4d} for {frac * 100:5.1f} % of the blocks : {ms:.3f} ms = {ms / base:.2f} x   workgroups that re-ran {fb * 100:5.1f} %   "
-          f"largest log2 denominator {top:6.1f}   error vs fp32 {err:.4f}", flush=True)
+          f"largest log2 denominator {top:6.1f}   error vs fp32 {err:.4f}   | exact form {ex:.3f} ms = {ex / base:.2f} x, error {err_ex:.4f}", flush=True)
