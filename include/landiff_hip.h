@@ -27,8 +27,8 @@ extern "C" {
  * compares ld_version() with the LD_ABI_VERSION it was built against before anything else (landiff_amd/_lib.py does).
  * 6: ld_reset and ld_attn_queue_poke were added.  7: ld_conv_cl_bf16_gn, ld_conv_gn_partials_size and
  * ld_groupnorm_stats_from_conv were added.  8: ld_gemm_qkv_heads_mxfp8 was added.
- * 9: ld_attn_fwd_bf16_exact was added. */
-#define LD_ABI_VERSION 9
+ * 9: ld_attn_fwd_bf16_exact was added.  10: ld_attn_last_fallbacks was added. */
+#define LD_ABI_VERSION 10
 
 int ld_version(void);
 const char* ld_last_error(void);
@@ -210,6 +210,15 @@ int ld_attn_queue_poke(int32_t set, uint32_t value, void* stream);
 /* Name of the kernel the calling thread's last ld_attn_fwd_bf16 launched ("" before the first call): the launcher picks
  * by shape and tuning environment, and measurement code must label what actually ran. */
 const char* ld_attn_last_kernel(void);
+
+/* How many 256-row query blocks of the calling thread's most recent ld_attn_fwd_bf16 launch had a row whose softmax denominator
+ * left the window of the max-free fast pass (2^-80 .. 2^110) and were recomputed by the running-max pass: a 4-byte value written to
+ * `out` (DEVICE memory) by a copy enqueued on `stream`, which must be the stream of that launch and must not have seen another
+ * attention launch since.  0 for launches by kernels without such a window (short or masked problems, the exact form); -1 when
+ * the launch has a window but kept no count (the static dispatch used under graph capture or beyond 64 streams per device).
+ * A caller that runs the same layers again and again (a sampler loop) reads it to switch a layer whose checkpoint leaves the
+ * window to ld_attn_fwd_bf16_exact (landiff_amd/dit.py: attn_exact="auto"; profiles/r06_attn_logit_sweep.txt for the prices). */
+int ld_attn_last_fallbacks(int32_t* out, void* stream);
 
 /* ---- tokenizer encoder side (ld_tokenize.hip) ---- */
 

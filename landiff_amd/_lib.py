@@ -44,7 +44,7 @@ class LlmLayer(Structure):
 
 
 _lib = None
-ABI_VERSION = 9          # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
+ABI_VERSION = 10         # LD_ABI_VERSION of include/landiff_hip.h that SIGNATURES below were written against
 
 I64 = c_int64
 I32 = c_int32
@@ -65,6 +65,7 @@ SIGNATURES: dict[str, list] = {
     "ld_attn_fwd_bf16": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_float, P, P, P, P, P],
     "ld_attn_fwd_bf16_exact": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_float, P, P, P, P, P],
     "ld_attn_last_kernel": [],
+    "ld_attn_last_fallbacks": [P, P],
     "ld_reset": [P],
     "ld_attn_queue_poke": [I32, c_uint32, P],
     "ld_gemv": [P, I64, I32, P, P, I32, P, P, I64, P, I64, I32, I64, I64, I64, I32, I32, P, c_float, P],

@@ -357,6 +357,23 @@ LD_API const char* ld_attn_last_kernel(void) { return g_attn_last_kernel; }
 
 int ld_attn_q64_exact_launch(const AttnParams& p, hipStream_t st);   // ld_attn_q64_exact.hip
 
+// Where the calling thread's last launch counts the query blocks that left the fast pass's window (ld_attn_last_fallbacks):
+// kind 0 = the kernel has no such window (running-max or two-pass softmax: nothing to count), 1 = counted at `src` (device address,
+// valid until the next launch on that stream), 2 = a max-free fast pass that keeps no count (static dispatch, 32-row tile).
+static thread_local const unsigned* g_attn_fb_src = nullptr;
+static thread_local int g_attn_fb_kind = 0;
+void ld_attn_set_fallback_source(const unsigned* src, int kind) { g_attn_fb_src = src; g_attn_fb_kind = kind; }
+
+LD_API int ld_attn_last_fallbacks(int32_t* out, void* stream) {
+  LD_REQUIRE(out, "ld_attn_last_fallbacks: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if (g_attn_fb_kind == 1) e = hipMemcpyAsync(out, g_attn_fb_src, 4, hipMemcpyDeviceToDevice, st);
+  else e = hipMemsetAsync(out, g_attn_fb_kind == 2 ? 0xFF : 0, 4, st);
+  if (e != hipSuccess) return ld_set_error(LD_ERR_LAUNCH, "ld_attn_last_fallbacks: %s", hipGetErrorString(e));
+  return LD_OK;
+}
+
 static int attn_fwd_impl(const void* Q, const void* K, const void* Vt, void* O,
                          int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Npad,
                          int64_t o_batch_stride, int64_t o_row_stride, float softmax_scale,
@@ -385,6 +402,7 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* Vt, void* O,
     var = e ? atoi(e) : 0;
   }
   hipStream_t st = (hipStream_t)stream;
+  ld_attn_set_fallback_source(nullptr, 0);          // (the pipelined launchers below say otherwise)
   const size_t s1 = 2 * STAGE_BYTES + 64;
   const int64_t nkt = (Nk + KT - 1) / KT;
   // LD_ATTN_Q64=0 (tuning knob): the 32-query-row wave tile of ld_attn_p16.hip instead of the 64-row one of ld_attn_q64.hip

@@ -483,6 +483,7 @@ __global__ __launch_bounds__(256, 2) void ld_attn_p16a_w4_kernel(AttnParams p, i
 }  // namespace
 
 void ld_attn_set_last_kernel(const char* name);   // ld_attn.hip
+void ld_attn_set_fallback_source(const unsigned* src, int kind);   // ld_attn.hip
 
 // LD_ATTN_SAFE=1 forces the running-max pass (testing); LD_ATTN_MSUM=0 takes the row sums by v_add_f32 (A/B timing).
 int ld_attn_p16_launch(const AttnParams& p, hipStream_t st) {
@@ -494,6 +495,7 @@ int ld_attn_p16_launch(const AttnParams& p, hipStream_t st) {
     const char* w = getenv("LD_ATTN_NW"); if (w && atoi(w) == 8) nw = 8;
   }
   static thread_local LdSmemCache c4{}, c4a{}, c8{};
+  ld_attn_set_fallback_source(nullptr, safe ? 0 : 2);       // a fast pass with a window, no count kept
   if (nw == 8 && msum) {
     if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_p16_w8_kernel, SMEM, &c8)) return rc;
     ld_attn_set_last_kernel(safe ? "ld_attn_p16_w8_kernel[safe pass forced]" : "ld_attn_p16_w8_kernel");

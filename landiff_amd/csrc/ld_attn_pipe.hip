@@ -345,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void ld_attn_pipe2_w8_kernel(AttnParams p, 
 }  // namespace
 
 void ld_attn_set_last_kernel(const char* name);   // ld_attn.hip
+void ld_attn_set_fallback_source(const unsigned* src, int kind);   // ld_attn.hip
 
 // LD_ATTN_SAFE=1 forces the running-max pass (testing / A-B timing); LD_ATTN_NW=4|8 picks the workgroup size.
 int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st) {
@@ -359,6 +360,7 @@ int ld_attn_pipe2_launch(const AttnParams& p, hipStream_t st) {
                        : ld_ensure_dyn_smem((const void*)ld_attn_pipe2_w8_kernel, SMEM, &c8)) return rc;
   const int qbw = nw * 32;
   dim3 grid((unsigned)((long)p.B * p.H * ((p.Npad + qbw - 1) / qbw)));
+  ld_attn_set_fallback_source(nullptr, safe ? 0 : 2);
   ld_attn_set_last_kernel(nw == 4 ? (safe ? "ld_attn_pipe2_w4_kernel[safe pass forced]" : "ld_attn_pipe2_w4_kernel")
                                   : (safe ? "ld_attn_pipe2_w8_kernel[safe pass forced]" : "ld_attn_pipe2_w8_kernel"));
   if (nw == 4) hipLaunchKernelGGL(ld_attn_pipe2_w4_kernel, grid, dim3(256), SMEM, st, p, safe);

@@ -503,6 +503,7 @@ LD_Q128_KERNEL(ld_attn_q128_s1n40_kernel, 40, 1)       // (LD_ATTN_NPRE=1040)
 }  // namespace
 
 void ld_attn_set_last_kernel(const char* name);   // ld_attn.hip
+void ld_attn_set_fallback_source(const unsigned* src, int kind);   // ld_attn.hip
 
 // LD_ATTN_SAFE=1 forces the running-max pass (testing); LD_ATTN_NPRE=36|52 picks the other exp2 splits (A/B timing).
 int ld_attn_q128_launch(const AttnParams& p, hipStream_t st) {
@@ -522,12 +523,14 @@ int ld_attn_q128_launch(const AttnParams& p, hipStream_t st) {
     if (k) {
       if (int rc = ld_ensure_dyn_smem((const void*)k, SMEM, c)) return rc;
       ld_attn_set_last_kernel(name);
+      ld_attn_set_fallback_source(nullptr, safe ? 0 : 2);
       hipLaunchKernelGGL(k, grid, dim3(256), SMEM, st, p, safe);
       return ld_check_launch("ld_attn_fwd_bf16(q128)");
     }
   }
   if (int rc = ld_ensure_dyn_smem((const void*)ld_attn_q128_kernel, SMEM, &c44)) return rc;
   ld_attn_set_last_kernel(safe ? "ld_attn_q128_kernel[safe pass forced]" : "ld_attn_q128_kernel");
+  ld_attn_set_fallback_source(nullptr, safe ? 0 : 2);
   hipLaunchKernelGGL(ld_attn_q128_kernel, grid, dim3(256), SMEM, st, p, safe);
   return ld_check_launch("ld_attn_fwd_bf16(q128)");
 }

@@ -58,6 +58,7 @@ __device__ unsigned g_q64_queue[Q64_QSETS][16];          // [set][0..7]: next bl
 __global__ __launch_bounds__(256, 2) void ld_attn_q64_dyn_kernel(AttnParams p, int force_safe, int total, int set) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* bcast = (int*)(smem + 8 * KTILE_BYTES + 32);
+  int* flags = (int*)(smem + 8 * KTILE_BYTES);             // the body's per-wave "a row left the window" words
   unsigned* Q = g_q64_queue[set];
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -65,8 +66,19 @@ __global__ __launch_bounds__(256, 2) void ld_attn_q64_dyn_kernel(AttnParams p, i
   const int per = total / 8, rem = total % 8;            // xcd_remap: XCD x owns [base(x), base(x) + cnt(x))
   auto base = [&](int x) { return x < rem ? x * (per + 1) : rem * (per + 1) + (x - rem) * per; };
   auto cnt = [&](int x) { return per + (x < rem ? 1 : 0); };
+#ifndef LD_Q64_NO_FBCOUNT
+  if (threadIdx.x == 0) flags[0] = flags[1] = flags[2] = flags[3] = 0;
+#endif
   for (;;) {
     if (threadIdx.x == 0) {
+#ifndef LD_Q64_NO_FBCOUNT
+      // Word 8 of the set: blocks of this launch that left the fast pass's window and were recomputed (ld_attn_last_fallbacks).
+      // The block just finished left its per-wave flags in LDS (the barrier that ends an iteration orders them); counted and
+      // cleared HERE, inside the one thread-0 section of the iteration: a second `if (threadIdx.x == 0)` at the end of the loop
+      // body gets threaded into this one by hipcc, which puts the barriers below inside a divergent loop (the launch hangs).
+      if ((flags[0] | flags[1] | flags[2] | flags[3]) != 0) __hip_atomic_fetch_add(&Q[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flags[0] = flags[1] = flags[2] = flags[3] = 0;      // (a block past Nq returns before it writes them)
+#endif
       int bid = -1;
       for (int kx = 0; kx < 8 && bid < 0; ++kx) {        // own range first, then the neighbours'
         const int x = (int)((xcc + kx) & 7u);
@@ -131,6 +143,7 @@ int q64_device_info(int* dev_out, unsigned** base_out, int* slots_out) {
 }  // namespace
 
 void ld_attn_set_last_kernel(const char* name);   // ld_attn.hip
+void ld_attn_set_fallback_source(const unsigned* src, int kind);   // ld_attn.hip
 
 // LD_ATTN_SAFE=1 forces the running-max pass (testing).  LD_ATTN_DYN=0: the hardware's round-robin dispatch of one workgroup per
 // query block instead of the dynamic form (the default for grids of at least four rounds of the chip's slots).
@@ -153,12 +166,14 @@ int ld_attn_q64_launch(const AttnParams& p, hipStream_t st) {
         hipError_t e = hipMemsetAsync(base + set * 16, 0, 64, st);
         if (e != hipSuccess) return ld_set_error(LD_ERR_LAUNCH, "ld_attn_fwd_bf16(q64 dynamic): zeroing counter set %d: %s", set, hipGetErrorString(e));
         ld_attn_set_last_kernel("ld_attn_q64_dyn_kernel");
+        ld_attn_set_fallback_source(base + set * 16 + 8, 1);
         hipLaunchKernelGGL(ld_attn_q64_dyn_kernel, dim3((unsigned)slots), dim3(256), SMEM, st, p, safe, total, set);
         return ld_check_launch("ld_attn_fwd_bf16(q64 dynamic)");
       }
     }
   }
   ld_attn_set_last_kernel(safe ? "ld_attn_q64_kernel[safe pass forced]" : "ld_attn_q64_kernel");
+  ld_attn_set_fallback_source(nullptr, safe ? 0 : 2);
   hipLaunchKernelGGL(ld_attn_q64_kernel, dim3((unsigned)total), dim3(256), SMEM, st, p, safe);
   return ld_check_launch("ld_attn_fwd_bf16(q64)");
 }

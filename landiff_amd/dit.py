@@ -78,17 +78,29 @@ class ControlDiTRunner:
 
     B = 2
 
-    def __init__(self, main_sd: dict, control_sd: dict, cfg: DiTConfig, device, fp8_gemm: bool = False, attn_exact: bool | None = None):
+    def __init__(self, main_sd: dict, control_sd: dict, cfg: DiTConfig, device, fp8_gemm: bool = False,
+                 attn_exact: "bool | str | None" = None):
         """fp8_gemm: BASELINE configs[4] -- the qkv / dense / 4h / 4h->h linears run on e4m3 operands; attention, norms,
         residual stream and every other layer stay bf16.  True / "row": weights quantised once per output channel,
         activations per row by a pass in front of each GEMM.  "mx": MXFP8 (one power-of-two scale per 32 K elements, applied
         by the MFMA); LayerNorm+modulate and the GELU epilogue write MXFP8 directly, only the attention output still takes
         a quantise pass.  Off for the headline metric and for every parity claim of the bf16 path."""
         self.cfg, self.dev, self.fp8 = cfg, device, fp8_gemm
-        # attn_exact (or LD_DIT_ATTN_EXACT=1): every attention launch through ld_attn_fwd_bf16_exact -- for checkpoints whose
-        # QK-LayerNorm gains push q.k/8 beyond the fast pass's window (~76): a fixed 1.55 x instead of data-dependent re-runs.
-        # Off by default: the default launch is exact inside the window and falls back by itself outside it.
-        self.attn_exact = (os.environ.get("LD_DIT_ATTN_EXACT", "0") == "1") if attn_exact is None else bool(attn_exact)
+        # attn_exact=True (or LD_DIT_ATTN_EXACT=1): every attention launch through ld_attn_fwd_bf16_exact -- for checkpoints whose
+        # QK-LayerNorm gains push q.k/8 beyond the fast pass's window (~76): a fixed 1.55 x instead of data-dependent re-runs
+        # (the default launch is exact inside the window and falls back by itself outside it, at up to 2.6 x).
+        # "auto" (or LD_DIT_ATTN_EXACT=auto): per layer -- every default launch reports how many of its 256-row blocks fell back
+        # (ld_attn_last_fallbacks); a layer where more than AUTO_EXACT_FRACTION of them did in a denoiser step takes the exact form
+        # from the step after next on (the counts of step s are read while step s + 1 runs: no host wait on the GPU's critical
+        # path, and the decision does not depend on timing).  The same checkpoint visits the same layers 50 times per video,
+        # so the first two steps pay for the measurement; the choice sticks to the runner (reset_attn_auto()).
+        # The default since it measured free on a checkpoint that never leaves the window (279.1 vs 279.4 ms per full-size step) and
+        # 312.6 vs 377.0 ms on one that does in a third of its layers (profiles/r06_dit_attn_auto_policy.txt); LD_DIT_ATTN_EXACT=0 /
+        # attn_exact=False: always the default launch, =1 / True: always the exact form.
+        if attn_exact is None:
+            attn_exact = {"1": True, "0": False}.get(os.environ.get("LD_DIT_ATTN_EXACT", "auto"), "auto")
+        self.attn_auto = attn_exact == "auto"
+        self.attn_exact = (not self.attn_auto) and bool(attn_exact)
         self.main = _Branch(main_sd, cfg, False, device, fp8_gemm)
         self.ctrl = _Branch(control_sd, cfg, True, device, fp8_gemm)
         c, B = cfg, self.B
@@ -137,6 +149,16 @@ class ControlDiTRunner:
         self.fuse_qkv = (self.fp8 in (False, None, "mx") and self.N % 8 == 0 and self.N >= 256 and c.head_dim == 64
                          and os.environ.get("LD_DIT_FUSE_QKV", "1") != "0")
         self._solo = True
+        self._attn_slot = 0                     # which layer's attention is being launched: control layers first, then main
+        self.exact_layers = set()               # slots switched to ld_attn_fwd_bf16_exact by the "auto" policy
+        if self.attn_auto:
+            L = c.layers_control + c.layers_main
+            self._fb = torch.zeros(L, device=device, dtype=torch.int32)
+            self._fb_host = [torch.zeros(L, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._fb_ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._fb_pending = [False, False]
+            self._fb_par = 0
+            self._attn_blocks = B * c.heads * ((self.Npad + 255) // 256)
         self.attn_events = None                 # bench.py: list of (start, end, solo) HIP events around every attention launch
         self.gemm_events = None                 # bench.py: list of (start, end, flops) around the large linears (qkv, dense, 4h, 4h->h, zero)
 
@@ -208,16 +230,42 @@ class ControlDiTRunner:
         ops.quantize_fp8(x, a8, self.sa)
         return ops.gemm_fp8(a8, self.sa, lw[name + "_w8"], lw[name + "_s"], out=out, bias=lw[name + "_b"], **epi)
 
+    AUTO_EXACT_FRACTION = 0.25      # profiles/r06_attn_logit_sweep.txt: beyond ~25 % of the blocks falling back, the exact form is cheaper
+
     def _attention(self):
         c, N = self.cfg, self.N
+        exact = self.attn_exact or (self._attn_slot in self.exact_layers)
         if self.attn_events is not None:       # bench.py: HIP events around every attention launch (roofline.achieved)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5, exact=self.attn_exact)
+            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5, exact=exact)
             e1.record()
             self.attn_events.append((e0, e1, self._solo))       # _solo: no other stream has work queued next to this launch
         else:
-            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5, exact=self.attn_exact)
+            ops.attn_fwd(self.q, self.k, self.vt, self.attn, N, N, c.head_dim ** -0.5, exact=exact)
+        if self.attn_auto and not exact:
+            ops.attn_last_fallbacks(self._fb[self._attn_slot:self._attn_slot + 1])     # (on the stream of the launch)
+
+    def _attn_auto_end_of_step(self):
+        """attn_exact="auto": hand this step's per-layer fallback counts to the host (asynchronously) and act on the previous step's."""
+        par = self._fb_par
+        self._fb_host[par].copy_(self._fb, non_blocking=True)
+        self._fb_ev[par].record()
+        self._fb_pending[par] = True
+        prev = 1 - par
+        if self._fb_pending[prev]:
+            self._fb_ev[prev].synchronize()          # the step before this one: done, or about to be -- the GPU stays one step ahead
+            self._fb_pending[prev] = False
+            limit = self.AUTO_EXACT_FRACTION * self._attn_blocks
+            self.exact_layers.update(i for i, n in enumerate(self._fb_host[prev].tolist()) if n > limit)
+        self._fb_par = prev
+
+    def reset_attn_auto(self):
+        """Forget which layers the "auto" policy switched to the exact attention form (a new checkpoint in the same runner)."""
+        self.exact_layers.clear()
+        if self.attn_auto:
+            self._fb.zero_()
+            self._fb_pending = [False, False]
 
     def _layer_mx(self, br: _Branch, i: int, h_in: torch.Tensor, h_out: torch.Tensor, control_add=None):
         """_layer with MXFP8 operands on the four large linears (fp8_gemm="mx")."""
@@ -249,6 +297,7 @@ class ControlDiTRunner:
     def _layer(self, br: _Branch, i: int, h_in: torch.Tensor, h_out: torch.Tensor, control_add=None):
         # with the two chains overlapped, only the main layers behind the last control state run with the GPU to themselves
         self._solo = (not self.overlap) or (br is self.main and i > self.cfg.layers_control)
+        self._attn_slot = i if br is self.ctrl else self.cfg.layers_control + i
         if self.fp8 == "mx":
             return self._layer_mx(br, i, h_in, h_out, control_add)
         c, lw = self.cfg, br.layers[i]
@@ -338,6 +387,12 @@ class ControlDiTRunner:
 
     def step(self, x: torch.Tensor, timestep: int, c_out: float, c_skip: float, cfg_scale: float, out: torch.Tensor):
         """x, out: [1, T, C, H, W] fp32.  out = CFG(denoised_uncond, denoised_cond)."""
+        r = self._step(x, timestep, c_out, c_skip, cfg_scale, out)
+        if self.attn_auto:
+            self._attn_auto_end_of_step()
+        return r
+
+    def _step(self, x, timestep, c_out, c_skip, cfg_scale, out):
         if self.overlap:
             return self._step_overlapped(x, timestep, c_out, c_skip, cfg_scale, out)
         self._time_emb(self.ctrl, timestep)

@@ -209,6 +209,14 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tens
     return out
 
 
+def attn_last_fallbacks(out: torch.Tensor) -> torch.Tensor:
+    """ld_attn_last_fallbacks: out int32 [1] on the device <- the number of 256-row query blocks of this thread's last attn_fwd launch
+    (on the current stream) that left the fast pass's window and were recomputed; 0: kernel without a window, -1: no count kept."""
+    assert out.dtype == torch.int32 and out.is_cuda and out.numel() >= 1
+    check(_lib.load().ld_attn_last_fallbacks(_ptr(out), _stream()), "ld_attn_last_fallbacks")
+    return out
+
+
 def reset() -> None:
     """ld_reset on the current stream: forget the stream -> counter-set assignments of the dynamic attention launch on the current
     device and zero the sets.  Only when no attention launch is in flight on another stream (after a device synchronise)."""

@@ -259,6 +259,10 @@ def test_attn_fallback_at_the_dit_shape_with_sink_keys(cuda, monkeypatch, T, fra
     out = torch.full((B, N, H * 64), float("nan"), device=cuda, dtype=torch.bfloat16)
     ops.attn_fwd(q, k, vt, out, N, N, 0.125)
     assert _last_kernel() == "ld_attn_q64_dyn_kernel"
+    # ld_attn_last_fallbacks: exactly the blocks that hold sink queries re-ran (none for a sink inside the window)
+    cnt = torch.full((1,), -7, device=cuda, dtype=torch.int32)
+    ops.attn_last_fallbacks(cnt)
+    assert int(cnt.item()) == (int(sel.sum().item()) if (T > 76 or T < -55) else 0), (int(cnt.item()), int(sel.sum().item()))
     # a logit of ~100 in bf16 operands carries an absolute error of ~0.4: the sink rows' probabilities move by tens of per cent of
     # tiny tails; the output (dominated by the sink's V row) stays within a few bf16 ulps of the range
     err = _err_vs_fp32(q, k, vt, out, N, [(0, 0), (1, 17), (1, 29)])
@@ -271,6 +275,11 @@ def test_attn_fallback_at_the_dit_shape_with_sink_keys(cuda, monkeypatch, T, fra
     ops.attn_fwd(q, k, vt, ref, N, N, 0.125)
     assert _last_kernel() == "ld_attn_q64_kernel"
     assert torch.equal(out, ref)
+    ops.attn_last_fallbacks(cnt)
+    assert int(cnt.item()) == -1          # the static dispatch has the window but keeps no count
+    ops.attn_fwd(q, k, vt, ref, N, N, 0.125, exact=True)
+    ops.attn_last_fallbacks(cnt)
+    assert int(cnt.item()) == 0           # the exact form has no window to leave
 
 
 @pytest.mark.parametrize("T,frac,sink_key", [(None, 0.0, 0), (90, 0.1, 0), (120, 1.0, 0), (90, 0.3, 17775), (-70, 0.2, 0)])
@@ -308,3 +317,6 @@ def test_attn_exact_form_small_and_masked_shapes_take_the_plain_kernel(cuda):
     ops.attn_fwd(q, k, vt, a, N, N, 0.125)
     ops.attn_fwd(q, k, vt, b, N, N, 0.125, exact=True)
     assert torch.equal(a, b) and _last_kernel().startswith("ld_attn_kernel")
+    cnt = torch.full((1,), -7, device=cuda, dtype=torch.int32)
+    ops.attn_last_fallbacks(cnt)
+    assert int(cnt.item()) == 0           # running-max kernel: nothing to fall back from

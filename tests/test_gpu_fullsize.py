@@ -166,6 +166,56 @@ def test_dit_layer_exact_attention_flag_at_full_shape(cuda, monkeypatch):
     assert d < 2e-2, d
     monkeypatch.setenv("LD_DIT_ATTN_EXACT", "1")
     assert ControlDiTRunner(sd_main, sd_ctrl, d1, cuda).attn_exact is True
+    monkeypatch.setenv("LD_DIT_ATTN_EXACT", "0")
+    r0 = ControlDiTRunner(sd_main, sd_ctrl, d1, cuda)
+    assert r0.attn_exact is False and r0.attn_auto is False
+    monkeypatch.delenv("LD_DIT_ATTN_EXACT")
+    ra = ControlDiTRunner(sd_main, sd_ctrl, d1, cuda)              # the default: per-layer choice from the launches' own counts
+    assert ra.attn_exact is False and ra.attn_auto is True
+
+
+def test_dit_attn_exact_auto_switches_only_the_layer_that_leaves_the_window(cuda):
+    """ControlDiTRunner(attn_exact="auto") at the BASELINE shape, 1 control + 1 main layer: the main layer's QK-LayerNorm gains are
+    scaled by 5 (row maxima of q.k/8 ~ 100: every block of its attention launch falls back), the control layer keeps unit gains.
+    The per-layer counts of step s are acted on while step s + 1 is enqueued: after three steps the main layer (slot 1) runs
+    ld_attn_fwd_bf16_exact, the control layer (slot 0) the default launch; the step output stays within bf16 rounding of the default
+    runner's (whose launch falls back inside the kernel) at every step; steps 3 and 4 of the auto runner are run-to-run identical."""
+    from landiff_amd.dit import ControlDiTRunner
+    from oracle_jobs import dit_layer_inputs
+    d1, sd_main, sd_ctrl, _, _ = dit_layer_inputs()
+    sd_main = dict(sd_main)
+    for nm in ("query", "key"):
+        kname = f"mixins.adaln_layer.{nm}_layernorm_list.0.weight"
+        sd_main[kname] = sd_main[kname] * 5.0
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, d1.latent_frames, d1.in_channels, d1.latent_h, d1.latent_w, generator=g).to(cuda)
+    ctx = torch.randn(1, d1.text_len, d1.text_dim, generator=g).to(torch.bfloat16).float()
+    sem = (0.5 * torch.randn(d1.latent_frames, d1.in_channels, d1.latent_h, d1.latent_w, generator=g)).to(torch.bfloat16)
+    outs = {}
+    for mode in (False, "auto"):
+        run = ControlDiTRunner(sd_main, sd_ctrl, d1, cuda, attn_exact=mode)
+        run.set_condition(ctx, sem)
+        res = []
+        for s in range(4):
+            out = torch.empty_like(x)
+            run.step(x, 500 - 10 * min(s, 2), -0.8, 0.6, 4.0, out)       # steps 2 and 3: the same call
+            res.append(out.cpu())
+            if mode == "auto":
+                # step 0's counts are read at the end of step 1: from step 2 on the main layer takes the exact form
+                assert run.exact_layers == (set() if s == 0 else {1}), (s, run.exact_layers)
+        outs[mode] = res
+        if mode == "auto":
+            assert int(run._fb_host[0][1]) == run._attn_blocks and int(run._fb_host[0][0]) == 0     # step 0: all blocks / none
+        del run
+    for s, (a, b) in enumerate(zip(outs[False], outs["auto"])):
+        assert torch.isfinite(b).all()
+        if s < 2:
+            assert torch.equal(a, b)                 # the same launches
+        else:                                        # near one-hot softmax rows: the two safe forms round a few of them apart
+            err = (a - b).abs()
+            print(f"step {s}: auto vs default runner: mean |d| {err.mean().item():.3e} of mean |x| {a.abs().mean().item():.3e}, max |d| {err.max().item():.3e}")
+            assert err.mean().item() <= 1e-2 * a.abs().mean().item()
+    assert torch.equal(outs["auto"][2], outs["auto"][3])
 
 
 def test_dit_multi_layer_step_full_shape_vs_oracle(cuda, oracle_bg):
