@@ -473,7 +473,11 @@ def main():
                                  if solo_rule else
                                  "control chain on a second stream and NO launch runs alone in this configuration: `achieved` is over all launches, "
                                  "whose event intervals include time shared with the other chain" if pipe.dit.overlap else
-                                 "serial step: every launch runs alone")}
+                                 "serial step: every launch runs alone"),
+                     # the runner's per-layer choice between the default launch and ld_attn_fwd_bf16_exact (landiff_amd/dit.py):
+                     # with these weights no layer leaves the fast pass's window, so every launch above is the default kernel
+                     "attn_policy": {"mode": "auto" if pipe.dit.attn_auto else ("exact" if pipe.dit.attn_exact else "default"),
+                                     "layers_on_exact_form": len(pipe.dit.exact_layers)}}
         # ---- per-stage achieved vs peak (rank 0) ----------------------------------------------------
         stages = {"dit_attention": {k: attn_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
         stages["dit_attention"]["seconds_per_step"] = round(attn_ms * 1e-3 * len(ev_all) / args.steps, 3)

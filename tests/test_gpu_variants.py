@@ -308,6 +308,7 @@ def test_bench_rccl_path_single_rank(cuda, launcher):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms"):
         assert k in res["roofline"], k
     assert res["roofline"]["achieved"] > 0 and res["roofline"]["launches"] > 0      # (tiny config: no launch runs alone -> all launches, labelled)
+    assert res["roofline"]["attn_policy"] == {"mode": "auto", "layers_on_exact_form": 0}
     assert res["roofline"]["bound"] == "mfma" and res["roofline"]["frac"] == pytest.approx(res["roofline"]["achieved"] / res["roofline"]["peak"], abs=1e-3)
     assert res["calibration"]["mfma_tflops"] > 100 and res["calibration"]["hbm_gbs"] > 500
     assert len(res["per_rank"]["frames_per_s"]) == 1
