@@ -1767,19 +1767,26 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_mx_kernel(GemmParams p) {
     s.s_bytes = clip(((long)(p.K >> 7) * srows - so) * 4);
     return s;
   };
-  uint32_t offA[2][2], offW[2][2];                        // [half][piece] byte offsets (the bf16 kernel's rows and swizzle)
+  // [piece] byte offsets of half 0 (the bf16 kernel's rows and swizzle); half 1 = + 64 rows of A / + 32 rows of W, added per use by
+  // an asm statement the compiler cannot hoist: with four more offset registers live through the K loop the gated-residual and
+  // GELU instantiations spilled one of them, and the reload's s_waitcnt vmcnt(0) drained the LDS-DMA queue once per K-tile
+  uint32_t offA[2], offW[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int lr = wave * 16 + i * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int tm = (lr >> 6) * 128 + h * 64 + (lr & 63);
-      const int tn = (lr >> 5) * 64 + h * 32 + (lr & 31);
-      offA[h][i] = (uint32_t)((long)tm * ldab + chunk * 16);
-      offW[h][i] = (uint32_t)((long)tn * ldwb + chunk * 16);
-    }
+    const int tm = (lr >> 6) * 128 + (lr & 63);
+    const int tn = (lr >> 5) * 64 + (lr & 31);
+    offA[i] = (uint32_t)((long)tm * ldab + chunk * 16);
+    offW[i] = (uint32_t)((long)tn * ldwb + chunk * 16);
   }
+  const int dA1 = (int)(64 * ldab), dW1 = (int)(32 * ldwb);
+  auto half_off = [](uint32_t o, int d, auto hc) -> uint32_t {
+    if constexpr (decltype(hc)::value == 0) return o;
+    uint32_t r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(o), "s"(d));
+    return r;
+  };
   const uint32_t offS = (uint32_t)(((wave & 3) * 64 + lane) * 4);     // this lane's row dword of the strip
   const int sslab = (int)(srows * 4);                     // bytes between consecutive K-tiles' scale slabs
   const int nk = p.K / KB;
@@ -1787,11 +1794,11 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_mx_kernel(GemmParams p) {
   Src src;
   auto stage_a = [&](const Src& s, auto bufc, auto hc, int kt) {
     constexpr int OFF = (decltype(bufc)::value ? BUF1 : 0) + decltype(hc)::value * SLOT;
-    stage_pieces<OFF>((const bf16_t*)s.a, s.a_bytes, my_piece, offA[decltype(hc)::value][0], offA[decltype(hc)::value][1], kt * KB);
+    stage_pieces<OFF>((const bf16_t*)s.a, s.a_bytes, my_piece, half_off(offA[0], dA1, hc), half_off(offA[1], dA1, hc), kt * KB);
   };
   auto stage_w = [&](const Src& s, auto bufc, auto gc, int kt) {
     constexpr int OFF = (decltype(bufc)::value ? BUF1 : 0) + (2 + decltype(gc)::value) * SLOT;
-    stage_pieces<OFF>((const bf16_t*)s.w, s.w_bytes, my_piece, offW[decltype(gc)::value][0], offW[decltype(gc)::value][1], kt * KB);
+    stage_pieces<OFF>((const bf16_t*)s.w, s.w_bytes, my_piece, half_off(offW[0], dW1, gc), half_off(offW[1], dW1, gc), kt * KB);
   };
   auto stage_s = [&](const Src& s, auto bufc, int kt) {     // 256 B per wave: the 64 row dwords (waves 0-3: A rows, 4-7: W rows)
     constexpr int OFF = SC_OFF + decltype(bufc)::value * 2048;
