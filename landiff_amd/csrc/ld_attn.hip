@@ -26,6 +26,12 @@
 //     tiles (no load, no MFMA) and apply the element mask only on the few straddling tiles.
 #include "ld_attn.h"
 
+#ifndef LD_ATTN_PLAIN_WPS
+#define LD_ATTN_PLAIN_WPS 3      // register budget (waves per SIMD) of the default instantiation
+#endif
+#define LD_STR_(x) #x
+#define LD_STR(x) LD_STR_(x)
+
 namespace {
 
 template <int TPS, bool DEFER, bool PRIO, bool MFMASUM, int WPS>   // WPS = waves/SIMD of the register budget
@@ -431,8 +437,8 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* Vt, void* O,
     g_attn_last_kernel = "ld_attn_kernel<1,true,false,false,4>";
     hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 4>), grid, block, s1, st, p);
   } else {
-    g_attn_last_kernel = "ld_attn_kernel<1,true,false,false,3>";
-    hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, 3>), grid, block, s1, st, p);
+    g_attn_last_kernel = "ld_attn_kernel<1,true,false,false," LD_STR(LD_ATTN_PLAIN_WPS) ">";
+    hipLaunchKernelGGL((ld_attn_kernel<1, true, false, false, LD_ATTN_PLAIN_WPS>), grid, block, s1, st, p);
   }
   return ld_check_launch("ld_attn_fwd_bf16");
 }

@@ -365,58 +365,92 @@ __device__ __forceinline__ void attn_q64_body(const AttnParams& p, int force_saf
   // group g + 1 in flight under the MFMAs of group g, one barrier per group.
   auto max_pass = [&]() {
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, 0x7fffffff, 0x00020000);
-    uint32_t ga[2];                                 // a K tile = 64 keys x 128 B = eight 1 KB pieces: two per wave
+    const int ng = (n + 3) / 4;
+    float m[4] = {NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG};
+    // Groups [g0, g1) with or without the key mask.  Each call computes its per-lane offsets from its own OPAQUE copy of the lane
+    // id, so that they are values of this loop only.  Shared -- with pass B, whose loop has no register to spare in this mode, or
+    // with the masked form, which keeps its scores in scratch -- they were spilled for their whole lifetime and reloaded in every
+    // trip of the unmasked loop, each reload behind an s_waitcnt vmcnt(0) that waited for the NEXT group's LDS-DMA
+    // (tools/audit_spills.py found it).
+    auto max_part = [&](int g0, int g1, auto maskc) {
+      int lane_m = lane;
+      asm volatile("" : "+v"(lane_m));
+      uint32_t ga[2];                               // a K tile = 64 keys x 128 B = eight 1 KB pieces: two per wave
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (wave * 2 + i) * 8 + (lane >> 3);
-      ga[i] = (uint32_t)(r * D + ((lane & 7) ^ q64_swz_k(r)) * 8) * 2u;
-    }
-    auto dma_group = [&](int set, int g) {        // tiles 4g .. 4g+3 (clamped: a re-fetch of the last tile) -> slots 4 set .. 4 set + 3
+      for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane_m >> 3);
+        ga[i] = (uint32_t)(r * D + ((lane_m & 7) ^ q64_swz_k(r)) * 8) * 2u;
+      }
+      const int l16m = lane_m & 15, h4m = lane_m >> 4;
+      int kofs_m[2];
+      {
+        const int key = 8 * (l16m >> 2) + (l16m & 3);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        int tile = 4 * g + t; tile = tile < n ? tile : n - 1;
+        for (int ks = 0; ks < 2; ++ks) kofs_m[ks] = key * 128 + (((ks * 4 + h4m) ^ q64_swz_k(key)) << 4);
+      }
+      auto dma_group = [&](int set, int g) {      // tiles 4g .. 4g+3 (clamped: a re-fetch of the last tile) -> slots 4 set .. 4 set + 3
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(smem + (4 * set + t) * KTILE_BYTES + (wave * 2 + i) * 1024),
-                                                   16, ga[i], tile * (KT * D * 2), 0, 0);
+        for (int t = 0; t < 4; ++t) {
+          int tile = 4 * g + t; tile = tile < n ? tile : n - 1;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(smem + (4 * set + t) * KTILE_BYTES + (wave * 2 + i) * 1024),
+                                                     16, ga[i], tile * (KT * D * 2), 0, 0);
+        }
+      };
+      if (g0 == 0 && g1 > 0) dma_group(0, 0);
+      for (int g = g0; g < g1; ++g) {
+        // this wave's pieces of group g have landed, its fragment reads of group g - 1 are done; then every wave's.  As ONE asm
+        // statement with a memory clobber + a scheduling barrier: the builtins alone do not keep hipcc from moving the fragment
+        // reads below (plain LDS loads -- it does not know that the LDS-DMA above writes what they read) across the barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        FENCE();
+        if (g + 1 < ng) dma_group((g + 1) & 1, g + 1);
+        FENCE();
+        const int set = g & 1;
+        // eight halves, straight-line: hipcc pipelines the fragment reads under the MFMAs
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int kg = 0; kg < 2; ++kg) {
+            bf16x8_t kf[2][2];
+            f32x4_t sc[2][4];
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks)
+                kf[bb][ks] = *(const bf16x8_t*)(smem + kofs_m[ks] + (4 * set + t) * KTILE_BYTES + kg * 4096 + bb * 512);
+            qk_half(sc, kf);                      // (C0 = 0 here: cinit is still zero)
+            if constexpr (decltype(maskc)::value) {
+              const int hh = 2 * (4 * g + t) + kg;      // (mask_half on this part's own lane values)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb) {
+                const int key0 = (hh >> 1) * KT + (hh & 1) * 32 + h4m * 8 + bb * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const bool dead = key0 + r >= p.Nk;
+#pragma unroll
+                  for (int qb = 0; qb < 4; ++qb) sc[bb][qb][r] = dead ? NEG_BIG : sc[bb][qb][r];
+                }
+              }
+            }
+            // plain fmaxf, not the v_max3_f32 asm helper: the operands are MFMA results, and nothing pads the MFMA -> VALU read
+            // hazard for an instruction inside an asm statement (a max3 scheduled right behind its MFMA read the accumulator's
+            // OLD value now and then: row maxima that missed a key, different from run to run)
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+              const float a = fmaxf(fmaxf(sc[0][qb][0], sc[0][qb][1]), fmaxf(sc[0][qb][2], sc[0][qb][3]));
+              const float c2 = fmaxf(fmaxf(sc[1][qb][0], sc[1][qb][1]), fmaxf(sc[1][qb][2], sc[1][qb][3]));
+              m[qb] = fmaxf(m[qb], fmaxf(a, c2));
+            }
+          }
       }
     };
-    float m[4] = {NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG};
-    auto group_max = [&](int set, int g, auto maskc) {      // eight halves, straight-line: hipcc pipelines the fragment reads under the MFMAs
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-          bf16x8_t kf[2][2];
-          f32x4_t sc[2][4];
-          load_kh(kf, 4 * set + t, kg);
-          qk_half(sc, kf);                        // (C0 = 0 here: cinit is still zero)
-          if constexpr (decltype(maskc)::value) mask_half(sc, 2 * (4 * g + t) + kg);
-          // plain fmaxf, not the v_max3_f32 asm helper: the operands are MFMA results, and nothing pads the MFMA -> VALU read
-          // hazard for an instruction inside an asm statement (a max3 scheduled right behind its MFMA read the accumulator's
-          // OLD value now and then: row maxima that missed a key, different from run to run)
-#pragma unroll
-          for (int qb = 0; qb < 4; ++qb) {
-            const float a = fmaxf(fmaxf(sc[0][qb][0], sc[0][qb][1]), fmaxf(sc[0][qb][2], sc[0][qb][3]));
-            const float c2 = fmaxf(fmaxf(sc[1][qb][0], sc[1][qb][1]), fmaxf(sc[1][qb][2], sc[1][qb][3]));
-            m[qb] = fmaxf(m[qb], fmaxf(a, c2));
-          }
-        }
-    };
-    const int ng = (n + 3) / 4;
-    dma_group(0, 0);
-    for (int g = 0; g < ng; ++g) {
-      // this wave's pieces of group g have landed, its fragment reads of group g - 1 are done; then every wave's.  As ONE asm
-      // statement with a memory clobber + a scheduling barrier: the builtins alone do not keep hipcc from moving the fragment
-      // reads below (plain LDS loads -- it does not know that the LDS-DMA above writes what they read) across the barrier
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      FENCE();
-      if (g + 1 < ng) dma_group((g + 1) & 1, g + 1);
-      FENCE();
-      // (tiles past the last one were fetched as copies of the last tile and are masked: harmless for a maximum)
-      if ((4 * g + 4) * KT <= p.Nk) group_max(g & 1, g, std::false_type{});
-      else group_max(g & 1, g, std::true_type{});
-    }
+    // Two loops, not one loop with a branch: only the last group can hold keys past Nk (tiles past the last one are fetched as
+    // copies of the last tile and masked too: harmless for a maximum)
+    const int ng_full = p.Nk / (4 * KT) < ng ? p.Nk / (4 * KT) : ng;
+    max_part(0, ng_full, std::false_type{});
+    max_part(ng_full, ng, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with the slots before pass B's prologue refills them
     FENCE();
 #pragma unroll
