@@ -41,17 +41,19 @@ class OracleJobs:
         self.dir = tempfile.mkdtemp(prefix="ld_oracle_jobs_")
         self.procs = {}
         self.parent_cpus, self.parent_threads = None, None   # what to give back to pytest once the last job has been joined
+        self.plan = {}                                        # name -> cores, for jobs that a test starts later (LATE_JOBS)
 
-    def start(self, name, cpus=None):
+    def start(self, name, cpus=None, arg=None):
         """cpus: the host cores this child (and its torch threads) may use -- the session hands every job its own share of the
         upper half of the cpuset and keeps the lower half for pytest itself, so that the oracle's OpenMP teams and the tests'
         own CPU work do not fight over cores (oversubscribed spin-waiting teams made one test 5x slower)."""
         if name in self.procs:
             return
+        cpus = cpus or self.plan.get(name)
         out = os.path.join(self.dir, name + ".pt")
         log = open(os.path.join(self.dir, name + ".log"), "w")
         env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")     # CPU only: the checker never sees the GPU
-        cmd = [sys.executable, os.path.join(ROOT, "tests", "oracle_jobs.py"), name, out]
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "oracle_jobs.py"), name, out] + ([arg] if arg else [])
         pre = None
         if cpus:
             env["OMP_NUM_THREADS"] = str(len(cpus)); env["LD_ORACLE_JOB_THREADS"] = str(len(cpus))
@@ -61,6 +63,8 @@ class OracleJobs:
 
     def result(self, name, timeout=1700.0):
         import torch
+        from oracle_jobs import LATE_JOBS
+        assert name in self.procs or name not in LATE_JOBS, f"oracle job {name} is started by {LATE_JOBS.get(name)}: select that test too"
         self.start(name)
         p, out, log = self.procs[name]
         rc = p.wait(timeout=timeout)
@@ -91,7 +95,10 @@ _JOBS = None
 
 # CPU-heavy tests whose oracle legs depend on device outputs (they cannot be started ahead): run them LAST, when the background jobs
 # have been joined and pytest has the whole cpuset again
-RUN_LAST = ("test_llm_full_size_prefill_and_decode_vs_oracle", "test_infer_video_entry_point_config0")
+RUN_LAST = ("test_llm_full_size_prefill_and_decode_vs_oracle",)
+# ... and the one whose oracle leg is long enough to be worth a child process of its own: it runs FIRST, hands its latent to the
+# child (LATE_JOBS) and a second test joins the result at the very end
+RUN_FIRST = ("test_infer_video_entry_point_config0",)
 
 
 def pytest_collection_modifyitems(session, config, items):
@@ -101,8 +108,9 @@ def pytest_collection_modifyitems(session, config, items):
     name = lambda it: it.nodeid.split("::")[-1].split("[")[0]
     join = [it for it in items if name(it) in CONSUMERS]
     last = [it for it in items if name(it) in RUN_LAST]
-    if join or last:
-        items[:] = [it for it in items if it not in join and it not in last] + join + last
+    first = [it for it in items if name(it) in RUN_FIRST]
+    if join or last or first:
+        items[:] = first + [it for it in items if it not in join and it not in last and it not in first] + join + last
 
 
 def pytest_collection_finish(session):
@@ -117,7 +125,8 @@ def pytest_collection_finish(session):
     if want and not session.config.option.collectonly:
         _JOBS = OracleJobs()
         # core plan: pytest keeps the lower half of its cpuset, the jobs split the upper half by weight (the VAE decode is the long one)
-        weight = {"vae_two_chunks": 4, "llm_two_blocks_fp32": 2, "llm_two_blocks_bf16": 2, "dit_3p3_eps": 2, "dit_layer": 1, "vae_level0": 2}
+        weight = {"vae_two_chunks": 4, "llm_two_blocks_fp32": 2, "llm_two_blocks_bf16": 2, "dit_3p3_eps": 2, "dit_layer": 1, "vae_level0": 2,
+                  "config0_frames": 3}
         cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
         plan = {}
         if len(cpus) >= 96:      # (a small host: no partition -- the jobs and pytest share the cores as the in-process legs used to)
@@ -131,8 +140,11 @@ def pytest_collection_finish(session):
             _JOBS.parent_cpus, _JOBS.parent_threads = set(cpus), torch.get_num_threads()
             os.sched_setaffinity(0, set(mine))
             torch.set_num_threads(max(1, min(len(mine), 64)))
+        from oracle_jobs import LATE_JOBS
+        _JOBS.plan = plan
         for name in want:
-            _JOBS.start(name, plan.get(name))
+            if name not in LATE_JOBS:                  # (those are started by their producer test, with its data)
+                _JOBS.start(name, plan.get(name))
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -6,7 +6,7 @@ Each job has an `*_inputs()` function that rebuilds its weights and inputs from 
 same function for the device side, so both sides see the same tensors without passing anything between processes -- and a
 `job_*()` function that returns what the test compares against.
 
-    python tests/oracle_jobs.py <job> <out.pt>      # what conftest.py runs
+    python tests/oracle_jobs.py <job> <out.pt> [<input.pt>]      # what conftest.py runs
 """
 import dataclasses
 import os
@@ -168,6 +168,19 @@ def job_vae_level0():
     return ref32, ref16
 
 
+# ---- test_facade.py::test_infer_video_entry_point_config0_frames_vs_oracle (started BY the entry-point test, with its own latent) ----
+def job_config0_frames(path):
+    """fp32 oracle (video [3, T, H, W] in [0, 1], uint8 frames) of the latent in `path` ({"vae_cfg", "vae_sd", "z32"}): PipelineOracle.frames
+    of BASELINE configs[0] -- 29 frames at 512 x 512 through the full-width VAE, ~80 s of host time that no longer sits in a test."""
+    from oracle.vae import VAEDecoderOracle, post_process, to_uint8_frames
+    d = torch.load(path, weights_only=False)
+    _threads(64)
+    with torch.no_grad():
+        rec = VAEDecoderOracle(d["vae_sd"], d["vae_cfg"], torch.float32).decode_latent(d["z32"].permute(0, 2, 1, 3, 4))
+        video = post_process(rec)[0]
+        return video.contiguous(), to_uint8_frames(video)
+
+
 JOBS = {
     "vae_two_chunks": job_vae_two_chunks,
     "llm_two_blocks_fp32": job_llm_two_blocks_fp32,
@@ -175,7 +188,10 @@ JOBS = {
     "dit_3p3_eps": job_dit_3p3_eps,
     "dit_layer": job_dit_layer,
     "vae_level0": job_vae_level0,
+    "config0_frames": job_config0_frames,
 }
+# jobs that a test starts itself (with an input file) instead of the session at collection time: name -> the test that starts it
+LATE_JOBS = {"config0_frames": "test_infer_video_entry_point_config0"}
 # which jobs a test (matched by the end of its node id) joins: conftest.py starts exactly these after collection
 CONSUMERS = {
     "test_vae_full_resolution_two_chunks_vs_oracle": ["vae_two_chunks"],
@@ -183,13 +199,14 @@ CONSUMERS = {
     "test_dit_multi_layer_step_full_shape_vs_oracle": ["dit_3p3_eps"],
     "test_dit_layer_full_shape_vs_oracle": ["dit_layer"],
     "test_vae_level0_resblock_full_resolution_vs_oracle": ["vae_level0"],
+    "test_infer_video_entry_point_config0_frames_vs_oracle": ["config0_frames"],
 }
 
 
 if __name__ == "__main__":
     name, out = sys.argv[1], sys.argv[2]
     t0 = time.perf_counter()
-    res = JOBS[name]()
+    res = JOBS[name](*sys.argv[3:4])
     torch.save({"result": res, "seconds": time.perf_counter() - t0}, out + ".tmp")
     os.replace(out + ".tmp", out)
     print(f"oracle job {name}: {time.perf_counter() - t0:.1f} s")
