@@ -221,6 +221,123 @@ __global__ __launch_bounds__(256) void ld_layernorm_mod_kernel(LnParams p) {
   else ln_mod2_apply<NC, false>(p, v, rstd, shc, scc, r0, has1, lane, nchunk);
 }
 
+// The DiT's block LayerNorms with MXFP8 output in the two-rows-per-wave, packed-math form of ld_layernorm_mod_kernel (round 6: the
+// one-row kernel below spends ~20 scalar VALU operations per element on bf16 roundings and ran at 2.7 TB/s; same bits).
+template <int NC, bool SAME>
+__device__ __forceinline__ void ln_mod2_apply_mx(const LnParams& p, f32x2_t (&v)[2][NC][4], const float (&rstd)[2], const bf16_t* const (&shift)[2],
+                                                 const bf16_t* const (&scale)[2], int r0, bool has1, int lane, int nchunk,
+                                                 unsigned char* mxs, long lds) {
+  const f32x2_t one2 = {1.0f, 1.0f};
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    const bool live = c < nchunk;
+    const int cc = live ? c : 0;                      // (lanes past the row's last chunk read chunk 0 and store nothing)
+    const u32x4_t ww = *(const u32x4_t*)(p.w + cc * 8), bw = *(const u32x4_t*)(p.b + cc * 8);
+    u32x4_t sh[2], sc[2];
+    sh[0] = *(const u32x4_t*)(shift[0] + cc * 8); sc[0] = *(const u32x4_t*)(scale[0] + cc * 8);
+    if (!SAME) { sh[1] = *(const u32x4_t*)(shift[1] + cc * 8); sc[1] = *(const u32x4_t*)(scale[1] + cc * 8); }
+    f32x2_t y[2][4];
+    float amax[2] = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x2_t w2 = unpack_bf16x2(ww[e]), b2 = unpack_bf16x2(bw[e]);
+      f32x2_t sp[2], st[2];
+#pragma unroll
+      for (int j = 0; j < (SAME ? 1 : 2); ++j) {
+        sp[j] = rbf2(unpack_bf16x2(sc[j][e]) + one2);
+        st[j] = unpack_bf16x2(sh[j][e]);
+      }
+      if (SAME) { sp[1] = sp[0]; st[1] = st[0]; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x2_t rs = {rstd[j], rstd[j]};
+        f32x2_t t = rbf2(v[j][i][e] * rs * w2 + b2);              // LayerNorm output in bf16
+        t = rbf2(rbf2(t * sp[j]) + st[j]);                        // modulate(), every op in bf16: the value the plain kernel stores
+        y[j][e] = t;
+        amax[j] = fmaxf(amax[j], fmaxf(fabsf(t[0]), fabsf(t[1])));
+      }
+    }
+    // a 32-element MX block = the chunks of four adjacent lanes; scale = smallest power of two >= amax / 448 (ld_quant_mxfp8_kernel)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float am = live ? amax[j] : 0.f;
+      am = fmaxf(am, __shfl_xor(am, 1, 64));
+      am = fmaxf(am, __shfl_xor(am, 2, 64));
+      if (!live || (j == 1 && !has1)) continue;
+      const uint32_t tb = __float_as_uint(am * (1.0f / 448.0f));
+      int sb = (int)((tb >> 23) & 0xffu) + ((tb & 0x7fffffu) != 0u ? 1 : 0);
+      sb = am > 0.f ? (sb < 1 ? 1 : (sb > 254 ? 254 : sb)) : 0;
+      const float inv = __uint_as_float((uint32_t)(254 - sb) << 23);
+      u32x2_t o;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(y[j][2 * h][0] * inv, y[j][2 * h][1] * inv, w, false);     // <= 448 by construction
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(y[j][2 * h + 1][0] * inv, y[j][2 * h + 1][1] * inv, w, true);
+        o[h] = w;
+      }
+      const long r = r0 + j;
+      *(u32x2_t*)((unsigned char*)p.out + r * p.ldo + c * 8) = o;
+      if ((c & 3) == 0) mxs[((long)(c >> 4) * lds + r) * 4 + ((c >> 2) & 3)] = (unsigned char)sb;   // [D/128][lds rows][4]
+    }
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void ld_layernorm_mx2_kernel(LnParams p, unsigned char* mxs, long lds) {
+  const int lane = threadIdx.x & 63;
+  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  if (r0 >= p.rows) return;
+  const bool has1 = r0 + 1 < p.rows;
+  const int nchunk = p.D >> 3;
+  u32x4_t raw[2][NC];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bf16_t* xr = (const bf16_t*)p.x + (long)(r0 + (has1 ? j : 0)) * p.ldx;      // odd row count: the last wave does its row twice
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      raw[j][i] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (c < nchunk) raw[j][i] = *(const u32x4_t*)(xr + c * 8);
+    }
+  }
+  const bf16_t* shift[2]; const bf16_t* scale[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = r0 + (has1 ? j : 0);
+    const int bb = r / p.rows_per_batch;
+    const bool txt = (r - bb * p.rows_per_batch) < p.text_len;
+    shift[j] = p.mod + bb * p.mod_bstride + (txt ? p.shift_txt : p.shift_img);
+    scale[j] = p.mod + bb * p.mod_bstride + (txt ? p.scale_txt : p.scale_img);
+  }
+  f32x2_t v[2][NC][4];
+  float rstd[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                      // (statistics exactly as ld_layernorm_mod_kernel takes them)
+    f32x2_t s2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[j][i][e] = unpack_bf16x2(raw[j][i][e]); s2 += v[j][i][e]; }
+    const float mean = wave_sum(s2[0] + s2[1]) / (float)p.D;
+    const f32x2_t mean2 = {mean, mean};
+    f32x2_t ss2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      if (lane + 64 * i < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[j][i][e] -= mean2; ss2 += v[j][i][e] * v[j][i][e]; }
+      }
+    }
+    rstd[j] = rsqrtf(wave_sum(ss2[0] + ss2[1]) / (float)p.D + p.eps);
+  }
+  const bf16_t* const shc[2] = {shift[0], shift[1]};
+  const bf16_t* const scc[2] = {scale[0], scale[1]};
+  if (shift[0] == shift[1] && scale[0] == scale[1]) ln_mod2_apply_mx<NC, true>(p, v, rstd, shc, scc, r0, has1, lane, nchunk, mxs, lds);
+  else ln_mod2_apply_mx<NC, false>(p, v, rstd, shc, scc, r0, has1, lane, nchunk, mxs, lds);
+}
+
 // LayerNorm (+ modulate) with MXFP8 output: the activation of the next MXFP8 GEMM is quantised where it is produced.
 template <int NC>   // chunks (of 8 elements) per lane
 __global__ __launch_bounds__(256) void ld_layernorm_mx_kernel(LnParams p, unsigned char* mxs, long lds) {
@@ -833,6 +950,17 @@ LD_API int ld_layernorm_mxfp8(const void* x, int64_t ldx, const void* w, const v
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int nc = (int)((D / 8 + 63) / 64);
+  static const bool fast_ok = !(getenv("LD_LN_FAST") && atoi(getenv("LD_LN_FAST")) == 0);
+  if (fast_ok && mod && w) {                          // the DiT's block LayerNorms: two rows per wave, packed math
+    grid = dim3((unsigned)((rows + 7) / 8));
+    switch (nc) {
+      case 1: hipLaunchKernelGGL(ld_layernorm_mx2_kernel<1>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;
+      case 2: hipLaunchKernelGGL(ld_layernorm_mx2_kernel<2>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;
+      case 3: hipLaunchKernelGGL(ld_layernorm_mx2_kernel<3>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;
+      default: hipLaunchKernelGGL(ld_layernorm_mx2_kernel<4>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;
+    }
+    return ld_check_launch("ld_layernorm_mxfp8");
+  }
   switch (nc) {
     case 1: hipLaunchKernelGGL(ld_layernorm_mx_kernel<1>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;
     case 2: hipLaunchKernelGGL(ld_layernorm_mx_kernel<2>, grid, block, 0, st, p, (unsigned char*)scales, (long)lds); break;

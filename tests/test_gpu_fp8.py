@@ -226,6 +226,19 @@ def test_fused_mxfp8_producers(cuda):
     s1 = torch.empty(D // 128, B * N, 4, device=cuda, dtype=torch.uint8)
     ops.layernorm_mxfp8(x, w, b, q1, s1, 1e-5, **kw)
     assert torch.equal(q1, q2) and torch.equal(s1, s2)
+    # an odd row count and a text / image boundary inside a wave's row pair (two rows per wave in the fused kernel), D = 1024
+    Bo, No, Do, To = 1, 77, 1024, 13
+    xo = torch.randn(Bo * No, Do, generator=g).to(cuda, BF)
+    wo = (1 + 0.1 * torch.randn(Do, generator=g)).to(cuda, BF); bo = (0.1 * torch.randn(Do, generator=g)).to(cuda, BF)
+    modo = (0.3 * torch.randn(Bo, 12 * Do, generator=g)).to(cuda, BF)
+    kwo = dict(mod=modo, mod_bstride=12 * Do, shift_img=0, scale_img=Do, shift_txt=6 * Do, scale_txt=7 * Do, rows_per_batch=No, text_len=To)
+    lno = torch.empty_like(xo)
+    ops.layernorm(xo, wo, bo, lno, 1e-5, **kwo)
+    qo2, so2 = ops.quantize_mxfp8(lno)
+    qo1 = torch.zeros(Bo * No, Do, device=cuda, dtype=torch.uint8)
+    so1 = torch.zeros(Do // 128, Bo * No, 4, device=cuda, dtype=torch.uint8)
+    ops.layernorm_mxfp8(xo, wo, bo, qo1, so1, 1e-5, **kwo)
+    assert torch.equal(qo1, qo2) and torch.equal(so1, so2)
     # GELU epilogue -> MXFP8
     M, Nn, K = 700, 7680, 1920
     a = torch.randn(M, K, generator=g).to(cuda, BF)
