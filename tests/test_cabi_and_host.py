@@ -405,6 +405,14 @@ def test_no_spill_traffic_inside_an_mfma_loop():
     # WITH the spills measured faster than 2 waves without (1.108 vs 1.211 ms on the TiTok shape, tools/titok_attn_time.py).
     found = [f for f in found if "ld_attn_kernel" not in f[0]]
     assert not found, found[:5]
+    # positive control: the audit must SEE a spill when there is one (tools/probe/spill_in_mfma_loop.hip cannot avoid it)
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        lib = os.path.join(tmp, "libspill.so")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                        os.path.join(ROOT, "tools", "probe", "spill_in_mfma_loop.hip"), "-o", lib], check=True, capture_output=True)
+        n_obj, n_k, found = mod.audit(lib)
+        assert n_obj == 1 and n_k == 1 and len(found) == 1 and found[0][0] == "ld_probe_spill_in_mfma_loop" and found[0][3] > 0, found
 
 
 def test_attention_q128_isa_audit():
