@@ -204,13 +204,15 @@ def test_attn_dynamic_queue_survives_poisoned_counters_and_stream_exhaustion(cud
     g = torch.cuda.CUDAGraph()
     out.zero_()
     s = torch.cuda.Stream()
+    cnt = torch.full((1,), 7, device=cuda, dtype=torch.int32)
     with torch.cuda.stream(s):
         with torch.cuda.graph(g, stream=s):
             ops.attn_fwd(q, k, vt, out, N, N, 0.125)
             assert _last_kernel() == "ld_attn_q64_kernel"
+            ops.attn_last_fallbacks(cnt)                         # (a captured node too: the static form keeps no count)
         g.replay()
     torch.cuda.synchronize()
-    assert torch.equal(out, ref)
+    assert torch.equal(out, ref) and int(cnt.item()) == -1
 
 
 # ---- round 6: the fallback at the headline shape, priced by tools/attn_logit_sweep.py (profiles/r06_attn_logit_sweep.txt) ----
