@@ -1836,8 +1836,22 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_mx_kernel(GemmParams p) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) b[j][ks] = *(const u32x4_t*)(smem + rdB[ks] + OFF + j * 2048);
   };
+#ifndef LD_MX_SCALE_BYTES
+#define LD_MX_SCALE_BYTES 1      // 1: the lane group's byte of a row dword by a byte load (12 ds_read_u8 + 9 shift-ors per K-tile); 0: dword loads + extract
+#endif
+  const int sbyteA = (wr * 128 + (lane & 15)) * 4 + (lane >> 4);       // byte g of this lane's row dword, block row 0 of half 0
+  const int sbyteB = 1024 + (wc * 64 + (lane & 15)) * 4 + (lane >> 4);
   auto read_scales = [&](auto bufc) {
     const char* sc = smem + SC_OFF + decltype(bufc)::value * 2048;
+#if LD_MX_SCALE_BYTES
+    const unsigned char* sa = (const unsigned char*)sc + sbyteA;
+    const unsigned char* sb = (const unsigned char*)sc + sbyteB;
+    sA[0] = (uint32_t)sa[0] | ((uint32_t)sa[64] << 8) | ((uint32_t)sa[128] << 16) | ((uint32_t)sa[192] << 24);
+    sB = (uint32_t)sb[0] | ((uint32_t)sb[64] << 8) | ((uint32_t)sb[128] << 16) | ((uint32_t)sb[192] << 24);     // byte 2 g + j: row g * 32 + j * 16
+    // (all three in P0: the strip is restaged for K-tile kt + 2 by the OTHER wave row's P1, which runs while this row is in P1 too --
+    //  reading the second half's scales only where they are first used, in P1, raced with that DMA and bought nothing)
+    sA[1] = (uint32_t)sa[256] | ((uint32_t)sa[320] << 8) | ((uint32_t)sa[384] << 16) | ((uint32_t)sa[448] << 24);
+#else
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       uint32_t pk = 0u;
@@ -1857,6 +1871,7 @@ __global__ __launch_bounds__(512, 2) void ld_gemm8p_mx_kernel(GemmParams p) {
         pk |= ((d >> sh8) & 0xffu) << (8 * (2 * g + j));
       }
     sB = pk;
+#endif
   };
   bool wave_live = true;
   auto frag = [](const u32x4_t (&f)[2]) {
